@@ -1,0 +1,210 @@
+/*
+ * mtbt_hip.h -- C ABI of libmtbt_hip.so: the MI355X (gfx950) kernels behind the drop-in
+ * `ConvNeXtBiFPNYOLO` module and its post-process.
+ *
+ * The reference has no FFI of its own: its operator API for this path is the `nn.Module`
+ * (`/root/reference/src/main_model.py:300-393`) calling torch.nn operators.  Each entry point below
+ * names the torch operator call sites (reference file:line) it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's storage);
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream); launches are
+ *     asynchronous, nothing here synchronises, allocates or keeps mutable global state, so the
+ *     library is re-entrant (autograd worker threads) and graph-capturable;
+ *   - activations are NHWC ("channels last"): element (n,y,x,c) of a tensor with C channels lives at
+ *     base + n*batch_stride + (y*W + x)*pixel_stride + c   (strides in ELEMENTS);
+ *     pixel_stride >= C lets a tensor be a channel slice of a wider buffer (concat-free C2f);
+ *   - return value: 0 = launched, <0 = MTBT_E* (nothing launched).  No exceptions cross the ABI.
+ */
+#ifndef MTBT_HIP_H
+#define MTBT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTBT_OK 0
+#define MTBT_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MTBT_EALIGN (-2)   /* pointer or stride not aligned as the kernel requires */
+#define MTBT_ELAUNCH (-3)  /* hipLaunchKernel reported an error */
+#define MTBT_EWORKSPACE (-4) /* caller workspace too small */
+
+/* storage / arithmetic types */
+#define MTBT_F32 0
+#define MTBT_BF16 1
+
+/* fused epilogue activations */
+#define MTBT_ACT_NONE 0
+#define MTBT_ACT_SILU 1 /* main_model.py:136 ; ultralytics Conv */
+#define MTBT_ACT_ELU 2  /* main_model.py:96 */
+#define MTBT_ACT_GELU 3 /* timm Mlp act (erf form), main_model.py:21-26 [upstream] */
+
+/* conv output addressing */
+#define MTBT_OUT_NHWC 0
+#define MTBT_OUT_CONVT2X2 1 /* ConvTranspose2d(k=2,s=2): GEMM row q*Cout+co -> pixel (2y+q/2, 2x+q%2), channel co */
+
+int mtbt_abi_version(void);
+/* "gfx950" */
+const char* mtbt_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense convolution as implicit GEMM on MFMA, fused affine + activation (+ residual) epilogue.
+ *   y = act(conv(x, w) * scale[k] + shift[k]) (+ res)
+ * Replaces every `nn.Conv2d(groups=1)` / `nn.Linear` / `nn.ConvTranspose2d(2,2)` + folded BatchNorm
+ * + activation on the path: ConvBlock (main_model.py:113-141), C2f/Bottleneck (:42-59, :144-173),
+ * DepthwiseConvBlock.pointwise (:84-93), BiFPN projections (:263-265), ConvNeXt downsample 2x2/2 and
+ * MLP fc1/fc2 (+GELU, +layer-scale residual) (:21-26 [timm]), ultralytics Conv / Conv2d / Proto
+ * (:324-328 [ultralytics]).
+ * dtype MTBT_BF16: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  MTBT_F32: v_mfma_f32_16x16x4_f32
+ * (exact fp32 products and sums) -- the parity mode.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtbt_conv_args {
+  const void* x;       /* [N,H,W,C] dtype */
+  const void* w;       /* [K][R][S][C] dtype (KRSC, C contiguous) */
+  void* y;             /* [N,Ho,Wo,K] out_dtype (or ConvT scatter target) */
+  const float* scale;  /* [K] or NULL (=1) */
+  const float* shift;  /* [K] or NULL (=0) */
+  const void* res;     /* residual, addressed like y, dtype; or NULL */
+  int64_t x_batch_stride, y_batch_stride, res_batch_stride; /* elements */
+  int32_t x_pixel_stride, y_pixel_stride, res_pixel_stride; /* elements */
+  int32_t N, H, W, C;  /* input; C % (64 bytes / sizeof(dtype)) == 0 */
+  int32_t K;           /* GEMM rows = output channels (4*Cout for CONVT2X2) */
+  int32_t R, S;        /* filter */
+  int32_t stride, pad; /* same in y and x */
+  int32_t Ho, Wo;      /* conv output size (before the CONVT scatter) */
+  int32_t dtype;       /* MTBT_F32 | MTBT_BF16: x, w, res */
+  int32_t out_dtype;   /* dtype of y: == dtype, or MTBT_F32 */
+  int32_t act;         /* MTBT_ACT_* */
+  int32_t out_mode;    /* MTBT_OUT_* */
+  int32_t tile_hint;   /* 0 = heuristic; else (TC<<16)|TP to force a tile (tests / tuning) */
+} mtbt_conv_args;
+
+int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ConvNeXt stem: Conv2d(3,Cout,4,stride 4,bias) on the caller's NCHW fp32 image + LayerNorm2d.
+ * Replaces timm `stem_0`/`stem_1` (main_model.py:21-26,34 [timm]).
+ *   x [N,3,H,W] f32 NCHW contiguous;  w [Cout][48] f32 (c,ky,kx order = torch layout flattened);
+ *   y [N,H/4,W/4,Cout] out_dtype NHWC dense.
+ * ------------------------------------------------------------------------------------------- */
+int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float* bias, const float* ln_w,
+                         const float* ln_b, float ln_eps, void* y, int N, int H, int W, int Cout,
+                         int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Depthwise k x k convolution (k in {3,7}, stride 1, pad k/2), NHWC dense, two epilogues:
+ *   ln_w != NULL : + bias, then LayerNorm over C (ConvNeXt block conv_dw + norm, [timm])
+ *   ln_w == NULL : * scale[c] + shift[c], then activation (ultralytics DWConv + BN + SiLU,
+ *                  Detect.cv3, main_model.py:324 [ultralytics])
+ *   w [k*k][C] f32 (tap-major);  C % 8 == 0, C <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+int mtbt_dwconv_nhwc(const void* x, const float* w, const float* bias, const float* ln_w,
+                     const float* ln_b, float ln_eps, const float* scale, const float* shift, int act,
+                     void* y, int N, int H, int W, int C, int ksize, int dtype, void* stream);
+
+/* LayerNorm over C of an NHWC dense tensor (timm LayerNorm2d in `stages_i.downsample.0`). */
+int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b, float eps, void* y,
+                        int64_t pixels, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BiFPN fusion node (main_model.py:211-213, :217-219, :228-232, :236-240):
+ *   y = sum_i wgt[i] * resample_i(x_i), i < n_in <= 3, accumulated left to right in fp32.
+ * resample: 0 identity, 1 bilinear x2 up (align_corners=False), 2 bilinear x0.5 (== 2x2 mean),
+ *           3 nearest x2 up, 4 max-pool 2x2  (3,4: src/model.py:58-70).
+ * add_weight_bug != 0 reproduces src/model.py:33-36 `sum(w_i + f_i)`.
+ * All tensors NHWC dense with C channels; y is [N,H,W,C].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtbt_fuse_args {
+  const void* x[3];
+  float wgt[3];
+  int32_t resample[3];
+  int32_t n_in;
+  void* y;
+  int32_t N, H, W, C; /* OUTPUT size; input i has H/2,W/2 (up), 2H,2W (down) or H,W */
+  int32_t dtype;
+  int32_t add_weight_bug;
+} mtbt_fuse_args;
+
+int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream);
+
+/* Global average pool over H*W then Linear(C, nout) (main_model.py:333-334, :364). y [N,nout] f32. */
+int mtbt_gap_fc(const void* x, const float* w, const float* b, float* y, int N, int HW, int C,
+                int nout, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Box decode (running_main_v3.py:264-290, :510-533 ; ultralytics Detect._inference/DFL/dist2bbox).
+ * Per level l: map [N,h_l,w_l,no] f32 NHWC with pixel stride `map_pixel_stride[l]`, no = 4*reg_max+nc.
+ *   ltrb = softmax(16 bins) . arange(16);  anchor = (x+.5, y+.5)
+ *   xyxy : boxes = (anchor -/+ ltrb) * stride[l]          (trainer decode)
+ *   xywh : boxes = ((x1y1+x2y2)/2, x2y2-x1y1) * stride[l]  (Detect eval; stride may be 0)
+ * Outputs (any may be NULL): boxes [N,A,4], scores = sigmoid(cls) [N,A,nc], best score [N,A],
+ * best label [N,A] (first max, as torch.max), and `preds_cat` [N, A, cat_stride] row-major with
+ * (box4, sigmoid cls) written at columns 0..4+nc-1 (the caller views it as [N,4+nc(+nm),A]).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtbt_decode_args {
+  const float* map[3];
+  int32_t h[3], w[3];
+  int32_t map_pixel_stride[3];
+  float stride[3];
+  int32_t n_levels, N, nc, reg_max;
+  int32_t xywh; /* 0: xyxy, 1: xywh */
+  float* boxes;
+  float* scores;
+  float* best_score;
+  int32_t* best_label;
+  float* preds_cat;
+  int32_t cat_stride;
+} mtbt_decode_args;
+
+int mtbt_decode_boxes(const mtbt_decode_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-image confidence filter + clamp + greedy NMS + top-k (running_main_v3.py:535-552 calling
+ * torchvision.ops.nms [upstream]).  One workgroup per image.  For image n:
+ *   cand = { a : best_score[n,a] > conf_th } in ascending a   (the reference's boolean-mask order)
+ *   boxes clamped to [0, clamp_max]; order = stable descending sort of scores;
+ *   greedy: keep i; suppress j if inter/(area_i+area_j-inter) > iou_th  (fp32, no FMA contraction);
+ *   stop after top_k kept.
+ * Outputs per image (row stride top_k): keep_idx = index into `cand` (== torchvision's return value),
+ * keep_anchor = a, out_boxes [top_k,4] (clamped), out_scores, out_labels; counts[n] = #kept;
+ * n_cand[n] = |cand|.  workspace: >= mtbt_nms_workspace_bytes(N, A) bytes.
+ * ------------------------------------------------------------------------------------------- */
+int64_t mtbt_nms_workspace_bytes(int N, int A);
+int mtbt_nms_batched(const float* boxes, const float* best_score, const int32_t* best_label, int N, int A,
+                     float conf_th, float iou_th, float clamp_max, int top_k, int64_t* keep_idx,
+                     int32_t* keep_anchor, float* out_boxes, float* out_scores, int64_t* out_labels,
+                     int32_t* counts, int32_t* n_cand, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Prototype x coefficient mask assembly (test_model.py:80-85 intended form) and the trainer's
+ * proto projector (running_main_v3.py:186, :251-257; evaluate_model.py:160-171), one kernel:
+ *   low[n,k,y,x] = sum_c coeff[n,k,c] * protos[n,y,x,c] (+ bias)
+ *   up = bilinear resize of low to (Hout,Wout), align_corners=False
+ *   logits (f32, may be NULL) = up ;  masks (u8, may be NULL) = sigmoid(up) > 0.5
+ * protos [N,hp,wp,nm] f32 NHWC dense.  coeff element (n,k,c) at coeff + n*coeff_batch_stride +
+ * k*coeff_k_stride + c*coeff_c_stride (so mc[N,A,nm] rows gathered through `gather_idx[n,k]`
+ * (anchor index, may be NULL => k itself) need no copy; projector: batch stride 0, K=1).
+ * Only k < counts[n] (counts may be NULL => K) is computed; padded slots k >= counts[n] are written as zeros.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtbt_mask_args {
+  const float* protos;
+  const float* coeff;
+  int64_t coeff_batch_stride, coeff_k_stride, coeff_c_stride;
+  const int32_t* gather_idx; /* [N,K] or NULL */
+  const int32_t* counts;     /* [N] or NULL */
+  float bias;
+  int32_t N, K, nm, hp, wp, Hout, Wout;
+  float* logits;  /* [N,K,Hout,Wout] or NULL */
+  uint8_t* masks; /* [N,K,Hout,Wout] or NULL */
+} mtbt_mask_args;
+
+int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream);
+
+/* dtype / layout helpers on the boundary */
+int mtbt_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTBT_HIP_H */

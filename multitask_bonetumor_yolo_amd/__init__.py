@@ -1,0 +1,10 @@
+"""MI355X-native multitask YOLO hot path: drop-in ConvNeXtBiFPNYOLO over hand-written HIP kernels.
+
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO          # == reference main_model.ConvNeXtBiFPNYOLO
+    from multitask_bonetumor_yolo_amd import postprocess                 # decode / NMS / masks on the GPU
+
+The HIP library (csrc/libmtbt_hip.so, C ABI in include/mtbt_hip.h) is built by
+`python -m multitask_bonetumor_yolo_amd.build`; nothing here falls back to the CPU.
+"""
+from . import postprocess  # noqa: F401
+from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv2, init_synthetic_  # noqa: F401

@@ -1,0 +1,99 @@
+"""ctypes binding of libmtbt_hip.so (C ABI: include/mtbt_hip.h).  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU = 0, 1, 2, 3
+OUT_NHWC, OUT_CONVT2X2 = 0, 1
+RES_ID, RES_UP_BILINEAR, RES_DOWN_MEAN, RES_UP_NEAREST, RES_MAXPOOL = 0, 1, 2, 3, 4
+
+ERRORS = {-1: "MTBT_EINVAL (bad argument / unsupported shape)", -2: "MTBT_EALIGN (misaligned pointer or stride)",
+          -3: "MTBT_ELAUNCH (kernel launch failed)", -4: "MTBT_EWORKSPACE (workspace too small)"}
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("res", C.c_void_p),
+        ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64), ("res_batch_stride", C.c_int64),
+        ("x_pixel_stride", C.c_int32), ("y_pixel_stride", C.c_int32), ("res_pixel_stride", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("K", C.c_int32),
+        ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("act", C.c_int32), ("out_mode", C.c_int32), ("tile_hint", C.c_int32),
+    ]
+
+
+class FuseArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p * 3), ("wgt", C.c_float * 3), ("resample", C.c_int32 * 3), ("n_in", C.c_int32),
+        ("y", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("dtype", C.c_int32), ("add_weight_bug", C.c_int32),
+    ]
+
+
+class DecodeArgs(C.Structure):
+    _fields_ = [
+        ("map", C.c_void_p * 3), ("h", C.c_int32 * 3), ("w", C.c_int32 * 3), ("map_pixel_stride", C.c_int32 * 3),
+        ("stride", C.c_float * 3), ("n_levels", C.c_int32), ("N", C.c_int32), ("nc", C.c_int32),
+        ("reg_max", C.c_int32), ("xywh", C.c_int32),
+        ("boxes", C.c_void_p), ("scores", C.c_void_p), ("best_score", C.c_void_p), ("best_label", C.c_void_p),
+        ("preds_cat", C.c_void_p), ("cat_stride", C.c_int32),
+    ]
+
+
+class MaskArgs(C.Structure):
+    _fields_ = [
+        ("protos", C.c_void_p), ("coeff", C.c_void_p),
+        ("coeff_batch_stride", C.c_int64), ("coeff_k_stride", C.c_int64), ("coeff_c_stride", C.c_int64),
+        ("gather_idx", C.c_void_p), ("counts", C.c_void_p), ("bias", C.c_float),
+        ("N", C.c_int32), ("K", C.c_int32), ("nm", C.c_int32), ("hp", C.c_int32), ("wp", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32), ("logits", C.c_void_p), ("masks", C.c_void_p),
+    ]
+
+
+# every symbol include/mtbt_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mtbt_abi_version": (C.c_int, []),
+    "mtbt_target_arch": (C.c_char_p, []),
+    "mtbt_conv2d_nhwc": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "mtbt_stem_conv4x4_ln": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "mtbt_dwconv_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                         + [C.c_int] * 6 + [C.c_void_p]),
+    "mtbt_layernorm_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_bifpn_fuse": (C.c_int, [C.POINTER(FuseArgs), C.c_void_p]),
+    "mtbt_gap_fc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "mtbt_decode_boxes": (C.c_int, [C.POINTER(DecodeArgs), C.c_void_p]),
+    "mtbt_nms_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "mtbt_nms_batched": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
+                         + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
+    "mtbt_mask_assemble": (C.c_int, [C.POINTER(MaskArgs), C.c_void_p]),
+    "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or raise: the product has no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m multitask_bonetumor_yolo_amd.build` "
+                               "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.mtbt_abi_version() != 1:
+            raise RuntimeError("libmtbt_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what}: {ERRORS.get(code, code)}")

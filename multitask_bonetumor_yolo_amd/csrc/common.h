@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 kernels of libmtbt_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mtbt_hip.h"
+
+typedef uint16_t bf16_t;  // storage type of a bf16 element
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// Round-to-nearest-even, NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> __device__ __forceinline__ float ld_elem(const T* p);
+template <> __device__ __forceinline__ float ld_elem<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_elem<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename T> __device__ __forceinline__ void st_elem(T* p, float v);
+template <> __device__ __forceinline__ void st_elem<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_elem<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 8 consecutive elements <-> 8 floats (two 16-B accesses for f32, one for bf16)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case MTBT_ACT_SILU: return v / (1.0f + __expf(-v));
+    case MTBT_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+    case MTBT_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define MTBT_LAUNCH_CHECK()                          \
+  do {                                               \
+    if (hipGetLastError() != hipSuccess) return MTBT_ELAUNCH; \
+  } while (0)

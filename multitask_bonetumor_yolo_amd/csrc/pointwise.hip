@@ -1,0 +1,484 @@
+// Bandwidth-bound kernels of the forward path (NHWC, 16-byte accesses, fp32 arithmetic):
+// ConvNeXt stem (4x4/4 conv + LayerNorm2d), depthwise k x k conv with LayerNorm or affine+activation
+// epilogue, LayerNorm over channels, BiFPN weighted fusion with resampling, GAP + Linear, casts.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Stem: y[n, oy, ox, :] = LN( W[Cout][3*4*4] . patch(n, oy, ox) + b )
+// Block = Cout*G threads, PIX consecutive output pixels per pass; the 48-float patch of each pixel
+// is staged in LDS with coalesced float4 reads of the NCHW image (4 floats = one kernel row).
+// ------------------------------------------------------------------------------------------------
+template <typename OT, int PIX>
+__global__ void stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                            const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, OT* __restrict__ y,
+                            int N, int H, int W, int Cout, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* patch = reinterpret_cast<float*>(smem);            // [PIX][48]
+  float* outv = patch + PIX * 48;                            // [PIX][Cout]
+  const int Ho = H / 4, Wo = W / 4;
+  const long total = (long)N * Ho * Wo;
+  const int tid = threadIdx.x;
+  const int ch = tid % Cout, grp = tid / Cout;
+  float wr[48];
+#pragma unroll
+  for (int i = 0; i < 48; ++i) wr[i] = w[ch * 48 + i];
+  const float bch = bias ? bias[ch] : 0.f;
+  const int nwaves = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
+
+  for (long base = (long)blockIdx.x * PIX; base < total; base += (long)gridDim.x * PIX) {
+    // stage patches: item = (pixel, c, ky) -> one float4
+    for (int it = tid; it < PIX * 12; it += blockDim.x) {
+      const int pix = it % PIX, cky = it / PIX;
+      const long gp = base + pix;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gp < total) {
+        const int n = (int)(gp / (Ho * Wo));
+        const int rem = (int)(gp - (long)n * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const int c = cky >> 2, ky = cky & 3;
+        v = *reinterpret_cast<const float4*>(x + (((long)n * 3 + c) * H + (oy * 4 + ky)) * W + ox * 4);
+      }
+      *reinterpret_cast<float4*>(patch + pix * 48 + cky * 4) = v;
+    }
+    __syncthreads();
+    for (int pix = grp; pix < PIX; pix += G) {
+      float acc = bch;
+      const float* pp = patch + pix * 48;
+#pragma unroll
+      for (int i = 0; i < 48; ++i) acc = fmaf(wr[i], pp[i], acc);
+      outv[pix * Cout + ch] = acc;
+    }
+    __syncthreads();
+    // LayerNorm over Cout per pixel: one wave per pixel
+    for (int pix = wave; pix < PIX; pix += nwaves) {
+      const long gp = base + pix;
+      if (gp >= total) break;
+      const float* o = outv + pix * Cout;
+      float s = 0.f;
+      for (int c = lane; c < Cout; c += 64) s += o[c];
+      const float mean = wave_sum(s) / Cout;
+      float q = 0.f;
+      for (int c = lane; c < Cout; c += 64) { const float d = o[c] - mean; q += d * d; }
+      const float rstd = rsqrtf(wave_sum(q) / Cout + eps);
+      for (int c = lane; c < Cout; c += 64) st_elem<OT>(y + gp * Cout + c, (o[c] - mean) * rstd * lnw[c] + lnb[c]);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise KS x KS, stride 1, pad KS/2.  Thread = (row y, block of XB consecutive x, 8-channel chunk);
+// the chunk index is the fastest thread index so a pixel's channels are read as one contiguous run.
+// Per filter row the thread loads XB+KS-1 input vectors once and slides the taps over them.
+// LN epilogue: per-pixel (mean, M2) partials over 8 channels are combined across the pixel's chunk
+// threads through LDS with the equal-count parallel-variance formula (single pass, no cancellation).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KS, bool LN>
+__global__ void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                              const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
+                              const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                              T* __restrict__ y, int N, int H, int W, int C, int slots) {
+  constexpr int XB = 4, PAD = KS / 2, SPAN = XB + KS - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int CH8 = C >> 3;
+  const int tid = threadIdx.x;
+  const int chunk = tid % CH8, slot = tid / CH8;
+  const int XBs = (W + XB - 1) / XB;
+  const long items = (long)N * H * XBs;
+  const long item = (long)blockIdx.x * slots + slot;
+  const bool live = item < items;
+  const long it = live ? item : 0;
+  const int xb = (int)(it % XBs);
+  const long ny = it / XBs;
+  const int yy = (int)(ny % H);
+  const int n = (int)(ny / H);
+  const int x0 = xb * XB;
+  const int c0 = chunk * 8;
+
+  float acc[XB][8];
+#pragma unroll
+  for (int i = 0; i < XB; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+
+  if (live) {
+    const T* xn = x + (long)n * H * W * C + c0;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {
+      const int iy = yy + ky - PAD;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      float in[SPAN][8];
+#pragma unroll
+      for (int j = 0; j < SPAN; ++j) {
+        const int ix = x0 + j - PAD;
+        if ((unsigned)ix < (unsigned)W) ld8<T>(xn + ((long)iy * W + ix) * C, in[j]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) in[j][e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        float wv[8];
+        ld8<float>(w + (long)(ky * KS + kx) * C + c0, wv);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(in[i + kx][e], wv[e], acc[i][e]);
+      }
+    }
+  }
+
+  if constexpr (LN) {
+    float bv[8], gw[8], gb[8];
+    ld8<float>(bias + c0, bv);
+    ld8<float>(lnw + c0, gw);
+    ld8<float>(lnb + c0, gb);
+    float2* red = reinterpret_cast<float2*>(smem);  // [slots][XB][CH8] (mean8, M2_8)
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      float m = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc[i][e] += bv[e]; m += acc[i][e]; }
+      m *= 0.125f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = acc[i][e] - m; m2 += d * d; }
+      red[(slot * XB + i) * CH8 + chunk] = make_float2(m, m2);
+    }
+    __syncthreads();
+    if (!live) return;
+    T* yo = y + (((long)n * H + yy) * W) * C + c0;
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      if (x0 + i >= W) break;
+      const float2* r = red + (slot * XB + i) * CH8;
+      float mean = 0.f;
+      for (int k = 0; k < CH8; ++k) mean += r[k].x;
+      mean /= CH8;
+      float m2 = 0.f;
+      for (int k = 0; k < CH8; ++k) { const float d = r[k].x - mean; m2 += r[k].y + 8.f * d * d; }
+      const float rstd = rsqrtf(m2 / C + eps);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (acc[i][e] - mean) * rstd * gw[e] + gb[e];
+      st8<T>(yo + (long)(x0 + i) * C, o);
+    }
+  } else {
+    if (!live) return;
+    float sc[8], sh[8];
+    ld8<float>(scale + c0, sc);
+    ld8<float>(shift + c0, sh);
+    T* yo = y + (((long)n * H + yy) * W) * C + c0;
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      if (x0 + i >= W) break;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = act_apply(acc[i][e] * sc[e] + sh[e], act);
+      st8<T>(yo + (long)(x0 + i) * C, o);
+    }
+  }
+}
+
+// LayerNorm over C, one wave per pixel, values held in registers between the two passes.
+template <typename T, int MAXV>
+__global__ void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                 float eps, T* __restrict__ y, long pixels, int C) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pix >= pixels) return;
+  const int CH8 = C >> 3;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < CH8) {
+      ld8<T>(x + pix * C + ch * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < CH8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < CH8) {
+      float gw[8], gb[8], o[8];
+      ld8<float>(w + ch * 8, gw);
+      ld8<float>(b + ch * 8, gb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gw[e] + gb[e];
+      st8<T>(y + pix * C + ch * 8, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BiFPN fusion node: thread = (output pixel, 8-channel chunk).
+// Bilinear x2 (align_corners=False): src = (dst+.5)/2-.5 clamped at 0; i0=floor, i1=min(i0+1,last).
+// Same association as torch: l0h*(l0w*v00+l1w*v01) + l1h*(l0w*v10+l1w*v11).
+// ------------------------------------------------------------------------------------------------
+struct FuseP {
+  const void* x[3];
+  float wgt[3];
+  int resample[3];
+  int n_in;
+  void* y;
+  int N, H, W, C;
+  int bug;
+};
+
+template <typename T>
+__device__ __forceinline__ void fuse_fetch(const T* src, int mode, int n, int y, int x, int H, int W, int C, int c0, float (&o)[8]) {
+  if (mode == 0) {
+    ld8<T>(src + (((long)n * H + y) * W + x) * C + c0, o);
+  } else if (mode == 1) {  // bilinear x2 up, source is H/2 x W/2
+    const int Hs = H >> 1, Ws = W >> 1;
+    float sy = (y + 0.5f) * 0.5f - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = (x + 0.5f) * 0.5f - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly1 = sy - y0, ly0 = 1.f - ly1, lx1 = sx - x0, lx0 = 1.f - lx1;
+    float a[8], b[8], c[8], d[8];
+    const T* base = src + (long)n * Hs * Ws * C + c0;
+    ld8<T>(base + ((long)y0 * Ws + x0) * C, a);
+    ld8<T>(base + ((long)y0 * Ws + x1) * C, b);
+    ld8<T>(base + ((long)y1 * Ws + x0) * C, c);
+    ld8<T>(base + ((long)y1 * Ws + x1) * C, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * b[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+  } else if (mode == 2 || mode == 4) {  // x0.5: source is 2H x 2W; 2x2 mean (bilinear) or max
+    const int Ws = W << 1;
+    float a[8], b[8], c[8], d[8];
+    const T* base = src + (long)n * (H << 1) * Ws * C + c0;
+    ld8<T>(base + ((long)(2 * y) * Ws + 2 * x) * C, a);
+    ld8<T>(base + ((long)(2 * y) * Ws + 2 * x + 1) * C, b);
+    ld8<T>(base + ((long)(2 * y + 1) * Ws + 2 * x) * C, c);
+    ld8<T>(base + ((long)(2 * y + 1) * Ws + 2 * x + 1) * C, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = (mode == 2) ? 0.5f * (0.5f * a[e] + 0.5f * b[e]) + 0.5f * (0.5f * c[e] + 0.5f * d[e])
+                         : fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+  } else {  // nearest x2 up
+    const int Hs = H >> 1, Ws = W >> 1;
+    ld8<T>(src + (((long)n * Hs + (y >> 1)) * Ws + (x >> 1)) * C + c0, o);
+  }
+}
+
+template <typename T>
+__global__ void fuse_kernel(const FuseP p) {
+  const int CH8 = p.C >> 3;
+  const long total = (long)p.N * p.H * p.W * CH8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int chunk = (int)(idx % CH8);
+    const long pix = idx / CH8;
+    const int x = (int)(pix % p.W);
+    const long ny = pix / p.W;
+    const int y = (int)(ny % p.H);
+    const int n = (int)(ny / p.H);
+    float acc[8], t[8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i >= p.n_in) break;
+      fuse_fetch<T>(reinterpret_cast<const T*>(p.x[i]), p.resample[i], n, y, x, p.H, p.W, p.C, chunk * 8, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float term = p.bug ? (p.wgt[i] + t[e]) : (p.wgt[i] * t[e]);
+        acc[e] = (i == 0) ? term : acc[e] + term;
+      }
+    }
+    st8<T>(reinterpret_cast<T*>(p.y) + pix * p.C + chunk * 8, acc);
+  }
+}
+
+// GAP over HW then Linear(C, nout); one block per image.
+template <typename T>
+__global__ void gap_fc_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                              float* __restrict__ y, int HW, int C, int nout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* part = reinterpret_cast<float*>(smem);  // [G][C]
+  float* mean = part + (blockDim.x / (C >> 3)) * C;
+  const int CH8 = C >> 3, G = blockDim.x / CH8;
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int chunk = tid % CH8, g = tid / CH8;
+  if (g < G) {
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
+    for (int p = g; p < HW; p += G) {
+      ld8<T>(x + ((long)n * HW + p) * C + chunk * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[g * C + chunk * 8 + e] = s[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < G; ++k) s += part[k * C + c];
+    mean[c] = s / HW;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+  for (int o = wave; o < nout; o += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += mean[c] * w[o * C + c];
+    s = wave_sum(s);
+    if (lane == 0) y[n * nout + o] = s + (b ? b[o] : 0.f);
+  }
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    st_elem<D>(d + i, ld_elem<S>(s + i));
+}
+
+inline unsigned grid_for(long work, int block) {
+  long g = (work + block - 1) / block;
+  return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                    float ln_eps, void* y, int N, int H, int W, int Cout, int out_dtype, void* stream) {
+  if (!x || !w || !ln_w || !ln_b || !y || N <= 0 || H % 4 || W % 4 || H <= 0 || W <= 0) return MTBT_EINVAL;
+  if (Cout <= 0 || Cout > 512 || Cout % 32) return MTBT_EINVAL;
+  if (!aligned16(x)) return MTBT_EALIGN;
+  constexpr int PIX = 32;
+  const int G = Cout <= 128 ? 2 : 1;
+  const int threads = Cout * G;
+  const long total = (long)N * (H / 4) * (W / 4);
+  const unsigned blocks = (unsigned)((total + PIX - 1) / PIX > 4096 ? 4096 : (total + PIX - 1) / PIX);
+  const size_t lds = (size_t)PIX * (48 + Cout) * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (out_dtype == MTBT_F32)
+    hipLaunchKernelGGL((stem_kernel<float, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (float*)y, N, H, W, Cout, G);
+  else if (out_dtype == MTBT_BF16)
+    hipLaunchKernelGGL((stem_kernel<bf16_t, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, N, H, W, Cout, G);
+  else return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_dwconv_nhwc(const void* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                float ln_eps, const float* scale, const float* shift, int act, void* y, int N, int H,
+                                int W, int C, int ksize, int dtype, void* stream) {
+  if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
+  if (ksize != 3 && ksize != 7) return MTBT_EINVAL;
+  const bool ln = ln_w != nullptr;
+  if (ln && (!ln_b || !bias)) return MTBT_EINVAL;
+  if (!ln && (!scale || !shift)) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(w)) return MTBT_EALIGN;
+  const int CH8 = C / 8;
+  int slots = 256 / CH8;
+  if (slots < 1) slots = 1;
+  const int threads = slots * CH8;
+  const long items = (long)N * H * ((W + 3) / 4);
+  const long blocks = (items + slots - 1) / slots;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  const size_t lds = ln ? (size_t)slots * 4 * CH8 * sizeof(float2) : 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DW_LAUNCH(T, KS, LN)                                                                                         \
+  hipLaunchKernelGGL((dwconv_kernel<T, KS, LN>), dim3((unsigned)blocks), dim3(threads), lds, s, (const T*)x, w, bias, ln_w, \
+                     ln_b, ln_eps, scale, shift, act, (T*)y, N, H, W, C, slots)
+  if (dtype == MTBT_F32) {
+    if (ksize == 7) { if (ln) DW_LAUNCH(float, 7, true); else DW_LAUNCH(float, 7, false); }
+    else { if (ln) DW_LAUNCH(float, 3, true); else DW_LAUNCH(float, 3, false); }
+  } else if (dtype == MTBT_BF16) {
+    if (ksize == 7) { if (ln) DW_LAUNCH(bf16_t, 7, true); else DW_LAUNCH(bf16_t, 7, false); }
+    else { if (ln) DW_LAUNCH(bf16_t, 3, true); else DW_LAUNCH(bf16_t, 3, false); }
+  } else return MTBT_EINVAL;
+#undef DW_LAUNCH
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b, float eps, void* y, int64_t pixels,
+                                   int C, int dtype, void* stream) {
+  if (!x || !w || !b || !y || pixels <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(w) || !aligned16(b)) return MTBT_EALIGN;
+  const long blocks = (pixels + 3) / 4;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int CH8 = C / 8;
+#define LN_LAUNCH(T, MAXV) \
+  hipLaunchKernelGGL((layernorm_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, w, b, eps, (T*)y, (long)pixels, C)
+  if (dtype == MTBT_F32) { if (CH8 <= 64) LN_LAUNCH(float, 1); else if (CH8 <= 128) LN_LAUNCH(float, 2); else LN_LAUNCH(float, 4); }
+  else if (dtype == MTBT_BF16) { if (CH8 <= 64) LN_LAUNCH(bf16_t, 1); else if (CH8 <= 128) LN_LAUNCH(bf16_t, 2); else LN_LAUNCH(bf16_t, 4); }
+  else return MTBT_EINVAL;
+#undef LN_LAUNCH
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream) {
+  if (!a || !a->y || a->n_in < 1 || a->n_in > 3 || a->N <= 0 || a->H <= 0 || a->W <= 0 || a->C <= 0 || a->C % 8) return MTBT_EINVAL;
+  FuseP p;
+  for (int i = 0; i < 3; ++i) {
+    p.x[i] = i < a->n_in ? a->x[i] : nullptr;
+    p.wgt[i] = a->wgt[i];
+    p.resample[i] = a->resample[i];
+    if (i < a->n_in) {
+      if (!a->x[i] || a->resample[i] < 0 || a->resample[i] > 4) return MTBT_EINVAL;
+      if ((a->resample[i] == 1 || a->resample[i] == 3) && ((a->H & 1) || (a->W & 1))) return MTBT_EINVAL;
+      if (!aligned16(a->x[i])) return MTBT_EALIGN;
+    }
+  }
+  if (!aligned16(a->y)) return MTBT_EALIGN;
+  p.n_in = a->n_in; p.y = a->y; p.N = a->N; p.H = a->H; p.W = a->W; p.C = a->C; p.bug = a->add_weight_bug;
+  const long total = (long)a->N * a->H * a->W * (a->C / 8);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == MTBT_F32) hipLaunchKernelGGL((fuse_kernel<float>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);
+  else if (a->dtype == MTBT_BF16) hipLaunchKernelGGL((fuse_kernel<bf16_t>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);
+  else return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_gap_fc(const void* x, const float* w, const float* b, float* y, int N, int HW, int C, int nout,
+                           int dtype, void* stream) {
+  if (!x || !w || !y || N <= 0 || HW <= 0 || C <= 0 || C % 8 || C > 2048 || nout <= 0) return MTBT_EINVAL;
+  if (!aligned16(x)) return MTBT_EALIGN;
+  const int CH8 = C / 8;
+  int G = 256 / CH8;
+  if (G < 1) G = 1;
+  int threads = ((G * CH8 + 63) / 64) * 64;
+  if (threads < 64) threads = 64;
+  // kernel derives G = blockDim / CH8; keep that equal to the G used for the LDS size
+  G = threads / CH8;
+  const size_t lds = (size_t)(G + 1) * C * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MTBT_F32) hipLaunchKernelGGL((gap_fc_kernel<float>), dim3(N), dim3(threads), lds, s, (const float*)x, w, b, y, HW, C, nout);
+  else if (dtype == MTBT_BF16) hipLaunchKernelGGL((gap_fc_kernel<bf16_t>), dim3(N), dim3(threads), lds, s, (const bf16_t*)x, w, b, y, HW, C, nout);
+  else return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_cast(const void* src, void* dst, int64_t n, int sd, int dd, void* stream) {
+  if (!src || !dst || n <= 0) return MTBT_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned g = grid_for(n, 256);
+  if (sd == MTBT_F32 && dd == MTBT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, (long)n);
+  else if (sd == MTBT_BF16 && dd == MTBT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, (long)n);
+  else if (sd == MTBT_F32 && dd == MTBT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, (long)n);
+  else if (sd == MTBT_BF16 && dd == MTBT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+  else return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}

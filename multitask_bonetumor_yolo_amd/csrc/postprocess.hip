@@ -1,0 +1,431 @@
+// Post-process kernels: box decode, per-image NMS, prototype x coefficient mask assembly.
+// Integer / index results (NMS) are bit-exact restatements of the reference's CPU arithmetic:
+// no FMA contraction, IEEE division, stable ordering.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Decode: 4 lanes per anchor, lane `side` owns one of (l,t,r,b): softmax over reg_max bins and the
+// expectation with arange; the quad exchanges the four distances by shuffles; the class part is
+// split over the quad and reduced to (best score, first best label).
+// ------------------------------------------------------------------------------------------------
+struct DecodeP {
+  const float* map[3];
+  int h[3], w[3], ld[3], off[4];
+  float stride[3];
+  int n_levels, N, nc, reg_max, xywh, A;
+  float* boxes;
+  float* scores;
+  float* best_score;
+  int* best_label;
+  float* preds_cat;
+  int cat_stride;
+};
+
+__global__ void decode_kernel(const DecodeP p) {
+  const long g = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int side = threadIdx.x & 3;
+  const long total = (long)p.N * p.A;
+  const bool live = g < total;
+  const long gg = live ? g : 0;
+  const int n = (int)(gg / p.A), a = (int)(gg - (long)n * p.A);
+  int l = 0;
+  if (p.n_levels > 1 && a >= p.off[1]) l = 1;
+  if (p.n_levels > 2 && a >= p.off[2]) l = 2;
+  const int cell = a - p.off[l];
+  const int w = p.w[l], hw = p.h[l] * w;
+  const int cy = cell / w, cx = cell - cy * w;
+  const float* row = p.map[l] + ((long)n * hw + cell) * p.ld[l];
+
+  // distribution of this lane's side
+  const float* d = row + side * p.reg_max;
+  float m = -INFINITY;
+  for (int i = 0; i < p.reg_max; ++i) m = fmaxf(m, d[i]);
+  float s = 0.f;
+  for (int i = 0; i < p.reg_max; ++i) s += expf(d[i] - m);
+  float dist = 0.f;
+  for (int i = 0; i < p.reg_max; ++i) dist += (expf(d[i] - m) / s) * (float)i;
+
+  const int qbase = (threadIdx.x & 63) & ~3;
+  const float dl = __shfl(dist, qbase + 0, 64), dt = __shfl(dist, qbase + 1, 64);
+  const float dr = __shfl(dist, qbase + 2, 64), db = __shfl(dist, qbase + 3, 64);
+  const float ax = cx + 0.5f, ay = cy + 0.5f, st = p.stride[l];
+  float out;
+  if (!p.xywh) {  // running_main_v3.py:100-110,529: dist2bbox(ltrb*stride, anchor*stride)
+    const float a_ = (side & 1) ? ay * st : ax * st;
+    const float d_ = (side == 0 ? dl : side == 1 ? dt : side == 2 ? dr : db) * st;
+    out = (side < 2) ? a_ - d_ : a_ + d_;
+  } else {        // ultralytics dist2bbox(xywh=True) in grid units, then * stride
+    const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;
+    out = (side == 0 ? (x1 + x2) / 2 : side == 1 ? (y1 + y2) / 2 : side == 2 ? x2 - x1 : y2 - y1) * st;
+  }
+  if (live) {
+    if (p.boxes) p.boxes[g * 4 + side] = out;
+    if (p.preds_cat) p.preds_cat[g * p.cat_stride + side] = out;
+  }
+  // classes
+  const float* cl = row + 4 * p.reg_max;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = side; c < p.nc; c += 4) {
+    const float sc = 1.0f / (1.0f + expf(-cl[c]));
+    if (live) {
+      if (p.scores) p.scores[g * p.nc + c] = sc;
+      if (p.preds_cat) p.preds_cat[g * p.cat_stride + 4 + c] = sc;
+    }
+    if (sc > best) { best = sc; bi = c; }
+  }
+#pragma unroll
+  for (int o = 1; o < 4; o <<= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (live && side == 0) {
+    if (p.best_score) p.best_score[g] = best;
+    if (p.best_label) p.best_label[g] = bi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NMS.  One 256-thread workgroup per image.
+//  1. stable compaction of { a : score[a] > conf_th } (ballot + wave prefix) -> cand list
+//  2. bitonic sort of 64-bit keys (~orderable(score) << 32 | cand index): descending score,
+//     ascending candidate index on ties == torch's stable descending sort
+//  3. greedy pass by wave 0, 64 sorted candidates per step: each lane tests its candidate against
+//     every box kept so far, the 64x64 in-chunk dependencies are bitmasks resolved by a scalar scan
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool iou_gt(const float4 bi, const float4 bj, float thr) {
+  // torchvision nms_kernel.cpp arithmetic, i = kept (earlier) box, j = candidate
+  const float iarea = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
+  const float jarea = __fmul_rn(__fsub_rn(bj.z, bj.x), __fsub_rn(bj.w, bj.y));
+  const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+  const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+  const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+  const float inter = __fmul_rn(w, h);
+  const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(iarea, jarea), inter));
+  return ovr > thr;
+}
+
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int NMS_KEPT_LDS = 1024;  // kept boxes cached in LDS; beyond that they are read back from out_boxes
+
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ score,
+                                                  const int* __restrict__ label, int A, float conf_th, float iou_th,
+                                                  float clamp_max, int top_k, long long* __restrict__ keep_idx,
+                                                  int* __restrict__ keep_anchor, float* __restrict__ out_boxes,
+                                                  float* __restrict__ out_scores, long long* __restrict__ out_labels,
+                                                  int* __restrict__ counts, int* __restrict__ n_cand, char* __restrict__ ws,
+                                                  long ws_per_image, int P2, int keys_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int wave_tot[4];
+  __shared__ int s_base;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* wsi = ws + (long)n * ws_per_image;
+  float4* sbox = reinterpret_cast<float4*>(wsi);                      // [A] sorted, clamped boxes
+  int* cand_anchor = reinterpret_cast<int*>(wsi + (long)A * 16);     // [A]
+  unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(wsi + (long)A * 20 + ((16 - ((long)A * 20) % 16) % 16));
+  float4* kept_lds = reinterpret_cast<float4*>(smem);                // [NMS_KEPT_LDS]
+  unsigned long long* keys = keys_in_lds ? reinterpret_cast<unsigned long long*>(smem + NMS_KEPT_LDS * 16) : gkeys;
+  const float* sc = score + (long)n * A;
+
+  // ---- 1. compaction (ascending anchor order) ----
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int a0 = 0; a0 < A; a0 += 256) {
+    const int a = a0 + tid;
+    const float v = a < A ? sc[a] : 0.f;
+    const bool f = a < A && v > conf_th;
+    const unsigned long long bal = __ballot(f);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int k = 0; k < wave; ++k) off += wave_tot[k];
+    if (f) {
+      const int pos = off + pre;
+      cand_anchor[pos] = a;
+      keys[pos] = ((unsigned long long)(~orderable(v)) << 32) | (unsigned)pos;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  const int M = s_base;
+  int P = 1;
+  while (P < M) P <<= 1;
+  for (int i = M + tid; i < P; i += 256) keys[i] = ~0ull;
+  __syncthreads();
+
+  // ---- 2. bitonic sort ascending over P keys ----
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long x = keys[lo], y = keys[hi];
+        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // sorted, clamped boxes to workspace
+  const float4* bx = reinterpret_cast<const float4*>(boxes) + (long)n * A;
+  for (int i = tid; i < M; i += 256) {
+    const int ci = (int)(keys[i] & 0xffffffffu);
+    float4 b = bx[cand_anchor[ci]];
+    b.x = fminf(fmaxf(b.x, 0.f), clamp_max); b.y = fminf(fmaxf(b.y, 0.f), clamp_max);
+    b.z = fminf(fmaxf(b.z, 0.f), clamp_max); b.w = fminf(fmaxf(b.w, 0.f), clamp_max);
+    sbox[i] = b;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- 3. greedy (wave 0) ----
+  long long* ki = keep_idx + (long)n * top_k;
+  int* ka = keep_anchor + (long)n * top_k;
+  float4* ob = reinterpret_cast<float4*>(out_boxes) + (long)n * top_k;
+  float* os = out_scores + (long)n * top_k;
+  long long* ol = out_labels + (long)n * top_k;
+  if (wave == 0) {
+    int nkept = 0;
+    for (int j0 = 0; j0 < M && nkept < top_k; j0 += 64) {
+      const int j = j0 + lane;
+      const bool have = j < M;
+      const float4 mine = have ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bool alive = have;
+      for (int k = 0; k < nkept; ++k) {
+        const float4 kb = k < NMS_KEPT_LDS ? kept_lds[k] : ob[k];
+        if (iou_gt(kb, mine, iou_th)) alive = false;
+      }
+      unsigned long long supp_by = 0ull;  // bit i set: earlier chunk member i would suppress me
+      for (int i = 0; i < 64; ++i) {
+        float4 o;
+        o.x = __shfl(mine.x, i, 64); o.y = __shfl(mine.y, i, 64); o.z = __shfl(mine.z, i, 64); o.w = __shfl(mine.w, i, 64);
+        if (i < lane && iou_gt(o, mine, iou_th)) supp_by |= 1ull << i;
+      }
+      const unsigned long long alive_mask = __ballot(alive);
+      const unsigned lo32 = (unsigned)supp_by, hi32 = (unsigned)(supp_by >> 32);
+      unsigned long long keepmask = 0ull;
+      for (int L = 0; L < 64; ++L) {
+        const unsigned long long sb = ((unsigned long long)__shfl(hi32, L, 64) << 32) | __shfl(lo32, L, 64);
+        if (((alive_mask >> L) & 1ull) && (sb & keepmask) == 0ull) keepmask |= 1ull << L;
+      }
+      const bool kept = (keepmask >> lane) & 1ull;
+      const int pos = nkept + __popcll(keepmask & ((1ull << lane) - 1ull));
+      if (kept && pos < top_k) {
+        const unsigned long long key = keys[j];
+        const int ci = (int)(key & 0xffffffffu);
+        const int a = cand_anchor[ci];
+        ki[pos] = ci;
+        ka[pos] = a;
+        ob[pos] = mine;
+        os[pos] = sc[a];
+        ol[pos] = label ? (long long)label[(long)n * A + a] : 0ll;
+        if (pos < NMS_KEPT_LDS) kept_lds[pos] = mine;
+      }
+      __threadfence_block();
+      nkept += __popcll(keepmask);
+      if (nkept > top_k) nkept = top_k;
+    }
+    for (int k = nkept + lane; k < top_k; k += 64) {
+      ki[k] = -1; ka[k] = -1; ob[k] = make_float4(0.f, 0.f, 0.f, 0.f); os[k] = 0.f; ol[k] = -1;
+    }
+    if (lane == 0) { counts[n] = nkept; if (n_cand) n_cand[n] = M; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mask assembly / proto projector.  Block = (tile, k, n); 64x64 output tile, 256 threads.
+//   low-res patch (+1 halo) = coeff . protos in fp32 -> LDS;  bilinear (align_corners=False) -> out.
+// ------------------------------------------------------------------------------------------------
+struct MaskP {
+  const float* protos;
+  const float* coeff;
+  long cbs, cks, ccs;
+  const int* gather;
+  const int* counts;
+  float bias;
+  int N, K, nm, hp, wp, Hout, Wout;
+  float* logits;
+  unsigned char* masks;
+  int tiles_x;
+};
+
+constexpr int MT = 64;  // output tile edge
+
+__global__ __launch_bounds__(256) void mask_kernel(const MaskP p) {
+  __shared__ float patch[(MT + 2) * (MT + 2)];
+  __shared__ float cf[64];
+  const int n = blockIdx.z, k = blockIdx.y, tid = threadIdx.x;
+  const int ty0 = (blockIdx.x / p.tiles_x) * MT, tx0 = (blockIdx.x % p.tiles_x) * MT;
+  if (p.counts && k >= p.counts[n]) {  // padded slot: defined (zero) output, no compute
+    const int row_ = tid >> 2, seg_ = tid & 3, oy_ = ty0 + row_, ox_ = tx0 + seg_ * 16;
+    if (oy_ >= p.Hout) return;
+    const long ob_ = (((long)n * p.K + k) * p.Hout + oy_) * p.Wout + ox_;
+    for (int e = 0; e < 16 && ox_ + e < p.Wout; ++e) {
+      if (p.logits) p.logits[ob_ + e] = 0.f;
+      if (p.masks) p.masks[ob_ + e] = 0;
+    }
+    return;
+  }
+  const float ry = (float)p.hp / (float)p.Hout, rx = (float)p.wp / (float)p.Wout;
+  auto src = [](int d, float r) { float s = (d + 0.5f) * r - 0.5f; return s < 0.f ? 0.f : s; };
+  const int ty1 = min(ty0 + MT, p.Hout) - 1, tx1 = min(tx0 + MT, p.Wout) - 1;
+  const int ly0 = (int)src(ty0, ry), lx0 = (int)src(tx0, rx);
+  const int ly1 = min((int)src(ty1, ry) + 1, p.hp - 1), lx1 = min((int)src(tx1, rx) + 1, p.wp - 1);
+  const int ph = ly1 - ly0 + 1, pw = lx1 - lx0 + 1;  // <= MT+2 for r <= 1
+  if (tid < p.nm) {
+    const long kk = p.gather ? p.gather[(long)n * p.K + k] : k;
+    cf[tid] = p.coeff[(long)n * p.cbs + kk * p.cks + tid * p.ccs];
+  }
+  __syncthreads();
+  const float* pr = p.protos + (long)n * p.hp * p.wp * p.nm;
+  for (int i = tid; i < ph * pw; i += 256) {
+    const int py = i / pw, px = i - py * pw;
+    const float* v = pr + ((long)(ly0 + py) * p.wp + (lx0 + px)) * p.nm;
+    float acc = 0.f;
+    for (int c = 0; c < p.nm; c += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(v + c);
+      acc = fmaf(cf[c], q.x, acc); acc = fmaf(cf[c + 1], q.y, acc);
+      acc = fmaf(cf[c + 2], q.z, acc); acc = fmaf(cf[c + 3], q.w, acc);
+    }
+    patch[py * pw + px] = acc + p.bias;
+  }
+  __syncthreads();
+  const int row = tid >> 2, seg = tid & 3;  // 64 rows x 4 segments of 16 px
+  const int oy = ty0 + row;
+  if (oy >= p.Hout) return;
+  const float sy = src(oy, ry);
+  const int y0 = (int)sy, y1 = y0 + (y0 < p.hp - 1 ? 1 : 0);
+  const float wy1 = sy - y0, wy0 = 1.f - wy1;
+  const float* r0 = patch + (y0 - ly0) * pw;
+  const float* r1 = patch + (y1 - ly0) * pw;
+  float o[16];
+  const int ox0 = tx0 + seg * 16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int ox = ox0 + e;
+    const float sx = src(ox < p.Wout ? ox : p.Wout - 1, rx);
+    const int x0 = (int)sx, x1 = x0 + (x0 < p.wp - 1 ? 1 : 0);
+    const float wx1 = sx - x0, wx0 = 1.f - wx1;
+    o[e] = wy0 * (wx0 * r0[x0 - lx0] + wx1 * r0[x1 - lx0]) + wy1 * (wx0 * r1[x0 - lx0] + wx1 * r1[x1 - lx0]);
+  }
+  const long obase = (((long)n * p.K + k) * p.Hout + oy) * p.Wout + ox0;
+  const bool full = ox0 + 16 <= p.Wout && (p.Wout % 16 == 0);
+  if (p.logits) {
+    if (full) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(p.logits + obase + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
+    } else {
+      for (int e = 0; e < 16 && ox0 + e < p.Wout; ++e) p.logits[obase + e] = o[e];
+    }
+  }
+  if (p.masks) {
+    unsigned char mb[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mb[e] = (1.0f / (1.0f + expf(-o[e])) > 0.5f) ? 1 : 0;
+    if (full) {
+      uint4 u;
+      u.x = mb[0] | (mb[1] << 8) | (mb[2] << 16) | ((unsigned)mb[3] << 24);
+      u.y = mb[4] | (mb[5] << 8) | (mb[6] << 16) | ((unsigned)mb[7] << 24);
+      u.z = mb[8] | (mb[9] << 8) | (mb[10] << 16) | ((unsigned)mb[11] << 24);
+      u.w = mb[12] | (mb[13] << 8) | (mb[14] << 16) | ((unsigned)mb[15] << 24);
+      *reinterpret_cast<uint4*>(p.masks + obase) = u;
+    } else {
+      for (int e = 0; e < 16 && ox0 + e < p.Wout; ++e) p.masks[obase + e] = mb[e];
+    }
+  }
+}
+
+inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+inline long nms_ws_per_image(int A) {
+  long b = (long)A * 20;
+  b += (16 - b % 16) % 16;
+  b += (long)pow2ceil(A) * 8;
+  return (b + 255) / 256 * 256;
+}
+
+}  // namespace
+
+extern "C" int mtbt_decode_boxes(const mtbt_decode_args* a, void* stream) {
+  if (!a || a->n_levels < 1 || a->n_levels > 3 || a->N <= 0 || a->nc <= 0 || a->reg_max <= 0 || a->reg_max > 64) return MTBT_EINVAL;
+  DecodeP p;
+  int A = 0;
+  for (int l = 0; l < 3; ++l) {
+    p.off[l] = A;
+    if (l < a->n_levels) {
+      if (!a->map[l] || a->h[l] <= 0 || a->w[l] <= 0 || a->map_pixel_stride[l] < 4 * a->reg_max + a->nc) return MTBT_EINVAL;
+      p.map[l] = a->map[l]; p.h[l] = a->h[l]; p.w[l] = a->w[l]; p.ld[l] = a->map_pixel_stride[l]; p.stride[l] = a->stride[l];
+      A += a->h[l] * a->w[l];
+    } else { p.map[l] = nullptr; p.h[l] = p.w[l] = 1; p.ld[l] = 0; p.stride[l] = 0.f; }
+  }
+  p.off[3] = A;
+  if (a->preds_cat && a->cat_stride < 4 + a->nc) return MTBT_EINVAL;
+  p.n_levels = a->n_levels; p.N = a->N; p.nc = a->nc; p.reg_max = a->reg_max; p.xywh = a->xywh; p.A = A;
+  p.boxes = a->boxes; p.scores = a->scores; p.best_score = a->best_score; p.best_label = a->best_label;
+  p.preds_cat = a->preds_cat; p.cat_stride = a->cat_stride;
+  const long total = (long)a->N * A;
+  const long blocks = (total + 63) / 64;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int64_t mtbt_nms_workspace_bytes(int N, int A) {
+  if (N <= 0 || A <= 0) return 0;
+  return (int64_t)N * nms_ws_per_image(A);
+}
+
+extern "C" int mtbt_nms_batched(const float* boxes, const float* best_score, const int32_t* best_label, int N, int A,
+                                float conf_th, float iou_th, float clamp_max, int top_k, int64_t* keep_idx,
+                                int32_t* keep_anchor, float* out_boxes, float* out_scores, int64_t* out_labels,
+                                int32_t* counts, int32_t* n_cand, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!boxes || !best_score || !keep_idx || !keep_anchor || !out_boxes || !out_scores || !out_labels || !counts || !workspace)
+    return MTBT_EINVAL;
+  if (N <= 0 || A <= 0 || top_k <= 0) return MTBT_EINVAL;
+  if (!aligned16(boxes) || !aligned16(out_boxes) || !aligned16(workspace)) return MTBT_EALIGN;
+  const long per = nms_ws_per_image(A);
+  if (workspace_bytes < (int64_t)N * per) return MTBT_EWORKSPACE;
+  const int P2 = pow2ceil(A);
+  const int keys_in_lds = (long)P2 * 8 <= 128 * 1024 ? 1 : 0;
+  const size_t lds = (size_t)NMS_KEPT_LDS * 16 + (keys_in_lds ? (size_t)P2 * 8 : 0);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return MTBT_ELAUNCH;
+  hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), boxes, best_score, best_label, A,
+                     conf_th, iou_th, clamp_max, top_k, reinterpret_cast<long long*>(keep_idx), keep_anchor, out_boxes, out_scores,
+                     reinterpret_cast<long long*>(out_labels), counts, n_cand, reinterpret_cast<char*>(workspace), per, P2, keys_in_lds);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream) {
+  if (!a || !a->protos || !a->coeff || (!a->logits && !a->masks)) return MTBT_EINVAL;
+  if (a->N <= 0 || a->K <= 0 || a->nm <= 0 || a->nm > 64 || a->nm % 4 || a->hp <= 0 || a->wp <= 0) return MTBT_EINVAL;
+  if (a->Hout < a->hp || a->Wout < a->wp) return MTBT_EINVAL;  // upsampling (or identity) only
+  if (a->K > 65535 || a->N > 65535) return MTBT_EINVAL;
+  if (!aligned16(a->protos)) return MTBT_EALIGN;
+  if (a->logits && !aligned16(a->logits)) return MTBT_EALIGN;
+  if (a->masks && !aligned16(a->masks)) return MTBT_EALIGN;
+  MaskP p;
+  p.protos = a->protos; p.coeff = a->coeff; p.cbs = a->coeff_batch_stride; p.cks = a->coeff_k_stride; p.ccs = a->coeff_c_stride;
+  p.gather = a->gather_idx; p.counts = a->counts; p.bias = a->bias;
+  p.N = a->N; p.K = a->K; p.nm = a->nm; p.hp = a->hp; p.wp = a->wp; p.Hout = a->Hout; p.Wout = a->Wout;
+  p.logits = a->logits; p.masks = a->masks;
+  p.tiles_x = (a->Wout + MT - 1) / MT;
+  const int tiles_y = (a->Hout + MT - 1) / MT;
+  hipLaunchKernelGGL(mask_kernel, dim3(p.tiles_x * tiles_y, a->K, a->N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_abi_version(void) { return 1; }
+extern "C" const char* mtbt_target_arch(void) { return "gfx950"; }

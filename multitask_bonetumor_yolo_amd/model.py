@@ -1,0 +1,612 @@
+"""Drop-in `ConvNeXtBiFPNYOLO` for MI355X: the reference's nn.Module interface
+(`/root/reference/src/main_model.py:300-393`; Segment-only variant `main_modelv2.py:300-385`) over
+hand-written HIP kernels (libmtbt_hip.so, C ABI in include/mtbt_hip.h).
+
+Same constructor, same submodule / parameter names (state_dicts and Lightning checkpoints load
+unchanged), same `forward(x, mode)` output layouts, same head `.training` flag handling (SURVEY
+F14).  The submodules below are PARAMETER CONTAINERS: they own the tensors under the reference's
+names and never run torch operators.  `forward` lowers the whole graph once per (shape, dtype,
+weights version) into a launch plan (engine.Plan) of C-ABI calls and replays it.
+
+There is no CPU path: tensors must live on an MI355X and the HIP library must be built.
+"""
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import Act, Plan, code_of, TORCH_DTYPE
+
+BN_MOMENTUM, BN_EPS = 0.9997, 4e-5  # main_model.py:95,135
+LN_EPS = 1e-6                       # timm ConvNeXt [upstream]
+DEPTHS, DIMS = (3, 3, 9, 3), (96, 192, 384, 768)
+
+
+class _Params(nn.Module):
+    """A module that only holds parameters; compute happens in the launch plan."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} is a parameter container of the HIP launch plan; "
+                           "call the top-level ConvNeXtBiFPNYOLO.forward")
+
+
+# ---- reference-owned blocks (main_model.py:42-296) -------------------------------------------------
+class ConvBlock(_Params):
+    def __init__(self, cin, cout, k=1, s=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, s, k // 2)
+        self.bn = nn.BatchNorm2d(cout, momentum=BN_MOMENTUM, eps=BN_EPS)
+        self.act = nn.SiLU()
+
+
+class Bottleneck(_Params):
+    def __init__(self, cin, cout, shortcut=True, kernel=(3, 3), e=0.5):
+        super().__init__()
+        hidden = int(cout * e)
+        self.cv1 = ConvBlock(cin, hidden, kernel[0], 1)
+        self.cv2 = ConvBlock(hidden, cout, kernel[1], 1)
+        self.add = shortcut and cin == cout
+
+
+class C2f(_Params):
+    def __init__(self, cin, cout, n=2, shortcut=False, e=0.5):
+        super().__init__()
+        self.c = int(cout * e)
+        self.cv1 = ConvBlock(cin, 2 * self.c, 1, 1)
+        self.cv2 = ConvBlock((2 + n) * self.c, cout, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, kernel=(3, 3), e=1.0) for _ in range(n))
+
+
+class DepthwiseConvBlock(_Params):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.depthwise = nn.Conv2d(cin, cout, 1, 1, 0, 1, groups=cin, bias=False)
+        self.pointwise = nn.Conv2d(cin, cout, 1, 1, 0, 1, 1, bias=False)
+        self.bn = nn.BatchNorm2d(cout, momentum=BN_MOMENTUM, eps=BN_EPS)
+        self.act = nn.ELU()
+
+
+class BiFPNUnit(_Params):
+    def __init__(self, feature_size=256, eps=1e-4):
+        super().__init__()
+        self.eps = eps
+        for lvl in ("p3_td", "p4_td", "p4_out", "p5_out"):
+            setattr(self, f"{lvl}_conv", DepthwiseConvBlock(feature_size, feature_size))
+            setattr(self, f"{lvl}_cf", C2f(feature_size, feature_size, shortcut=False))
+        # uninitialised in the reference (main_model.py:191-192); load real values
+        self.w1 = nn.Parameter(torch.Tensor(2, 2), requires_grad=True)
+        self.w2 = nn.Parameter(torch.Tensor(3, 2), requires_grad=True)
+
+
+class BiFPN(_Params):
+    def __init__(self, size: List[int], feature_size=256, num_layers=3, eps=1e-4):
+        super().__init__()
+        if len(size) != 3:
+            raise ValueError(f"BiFPN expects 3 input sizes for C3, C4, C5 projections, got {len(size)}")
+        self.p3_proj = ConvBlock(size[0], feature_size, 1)
+        self.p4_proj = ConvBlock(size[1], feature_size, 1)
+        self.p5_proj = ConvBlock(size[2], feature_size, 1)
+        self.num_layers, self.feature_size = num_layers, feature_size
+        self.bifpn_units = nn.Sequential(*[BiFPNUnit(feature_size, eps=eps) for _ in range(num_layers)])
+
+
+# ---- timm ConvNeXt-T feature extractor, parameter names of FeatureListNet [upstream] ---------------
+class _Mlp(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.fc1 = nn.Linear(d, 4 * d)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(4 * d, d)
+
+
+class _CNBlock(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(d, d, 7, 1, 3, groups=d, bias=True)
+        self.norm = nn.LayerNorm(d, eps=LN_EPS)
+        self.mlp = _Mlp(d)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(d))
+
+
+class _CNStage(_Params):
+    def __init__(self, cin, cout, depth, downsample):
+        super().__init__()
+        self.downsample = (nn.Sequential(nn.LayerNorm(cin, eps=LN_EPS), nn.Conv2d(cin, cout, 2, 2))
+                           if downsample else nn.Identity())
+        self.blocks = nn.Sequential(*[_CNBlock(cout) for _ in range(depth)])
+
+
+class _CNFeatures(_Params):
+    def __init__(self):
+        super().__init__()
+        self.stem_0 = nn.Conv2d(3, DIMS[0], 4, 4)
+        self.stem_1 = nn.LayerNorm(DIMS[0], eps=LN_EPS)
+        prev = DIMS[0]
+        for i, (d, n) in enumerate(zip(DIMS, DEPTHS)):
+            setattr(self, f"stages_{i}", _CNStage(prev, d, n, i > 0))
+            prev = d
+
+
+class ConvNeXtTiny(_Params):
+    """main_model.py:12-38."""
+
+    def __init__(self, pretrained: bool = True):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError("pretrained_backbone=True would download timm weights (main_model.py:21-26); there is "
+                               "no network: build with pretrained_backbone=False and load_state_dict() a checkpoint")
+        self.body = _CNFeatures().eval()
+        self.c2f_p3 = C2f(192, 256)
+        self.c2f_p4 = C2f(384, 384)
+        self.c2f_p5 = C2f(768, 512)
+        self.out_channels = list(DIMS[1:])
+
+
+# ---- ultralytics heads, parameter names of Detect / Segment / Proto / DFL [upstream] ---------------
+class _UConv(_Params):
+    def __init__(self, c1, c2, k=1, g=1):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, 1, k // 2, groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU()
+
+
+class _DFL(_Params):
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+
+class _Proto(_Params):
+    def __init__(self, c1, c_=256, c2=32):
+        super().__init__()
+        self.cv1 = _UConv(c1, c_, 3)
+        self.upsample = nn.ConvTranspose2d(c_, c_, 2, 2, 0, bias=True)
+        self.cv2 = _UConv(c_, c_, 3)
+        self.cv3 = _UConv(c_, c2)
+
+
+class Detect(_Params):
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        self.nc, self.nl, self.reg_max = nc, len(ch), 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)  # never set by the reference
+        c2 = max(16, ch[0] // 4, self.reg_max * 4)
+        c3 = max(ch[0], min(nc, 100))
+        self.cv2 = nn.ModuleList(
+            nn.Sequential(_UConv(x, c2, 3), _UConv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(
+            nn.Sequential(nn.Sequential(_UConv(x, x, 3, g=x), _UConv(x, c3, 1)),
+                          nn.Sequential(_UConv(c3, c3, 3, g=c3), _UConv(c3, c3, 1)),
+                          nn.Conv2d(c3, nc, 1)) for x in ch)
+        self.dfl = _DFL(self.reg_max)
+
+
+class Segment(Detect):
+    def __init__(self, nc=80, nm=32, npr=256, ch=()):
+        super().__init__(nc, ch)
+        self.nm, self.npr = nm, npr
+        self.proto = _Proto(ch[0], npr, nm)
+        c4 = max(ch[0] // 4, nm)
+        self.cv4 = nn.ModuleList(
+            nn.Sequential(_UConv(x, c4, 3), _UConv(c4, c4, 3), nn.Conv2d(c4, nm, 1)) for x in ch)
+
+
+# ---- weight folding (eval-mode BatchNorm folds into the conv epilogue) -----------------------------
+def _bn_fold(bn: nn.BatchNorm2d, conv_bias=None):
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().float() * scale
+    return scale, shift
+
+
+def _krsc(w: torch.Tensor) -> torch.Tensor:
+    """[K,C,R,S] -> [K, R*S*C]."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+class _Lowering:
+    """Builds the launch plan for one (batch, size, dtype, mode) from the module tree."""
+
+    def __init__(self, model, x: torch.Tensor, code: int):
+        self.m = model
+        self.code = code
+        self.dt = TORCH_DTYPE[code]
+        self.p = Plan(x.device)
+        self.x = x
+
+    # constants
+    def W(self, t):  # weights in compute dtype
+        return self.p.const(t.float(), self.dt)
+
+    def F(self, t):  # fp32 vectors
+        return self.p.const(t.float(), torch.float32)
+
+    @staticmethod
+    def _need_eval(bn, where):
+        if bn.training:
+            raise NotImplementedError(
+                f"{where}: BatchNorm in train mode (batch statistics) is not lowered to HIP yet; use model.eval() "
+                "and mode='infer' (see DESIGN.md, scope)")
+
+    # -- building blocks --
+    def convblock(self, x: Act, mod, y: Act = None, name=""):
+        """reference ConvBlock (conv bias) or ultralytics Conv (no bias): conv + BN(eval) + SiLU."""
+        conv, bn = mod.conv, mod.bn
+        self._need_eval(bn, name)
+        k = conv.kernel_size[0]
+        scale, shift = _bn_fold(bn, conv.bias)
+        if y is None:
+            y = self.p.new(x.N, x.H, x.W, conv.out_channels, self.code)
+        self.p.conv(x, self.W(_krsc(conv.weight)), y, R=k, S=k, stride=1, pad=k // 2, scale=self.F(scale),
+                    shift=self.F(shift), act=L.ACT_SILU, name=name)
+        return y
+
+    def conv_plain(self, x: Act, conv: nn.Conv2d, y: Act, name=""):
+        k = conv.kernel_size[0]
+        self.p.conv(x, self.W(_krsc(conv.weight)), y, R=k, S=k, stride=conv.stride[0], pad=conv.padding[0],
+                    shift=self.F(conv.bias) if conv.bias is not None else None, name=name)
+        return y
+
+    def dwblock(self, x: Act, mod: _UConv, name=""):
+        """ultralytics DWConv: depthwise 3x3 + BN + SiLU."""
+        self._need_eval(mod.bn, name)
+        scale, shift = _bn_fold(mod.bn)
+        w = self.F(mod.conv.weight.detach().reshape(x.C, 9).t())
+        y = self.p.new(x.N, x.H, x.W, x.C, self.code)
+        self.p.dwconv(x, w, y, 3, scale=self.F(scale), shift=self.F(shift), act=L.ACT_SILU, name=name)
+        return y
+
+    def c2f(self, x: Act, mod: C2f, name=""):
+        """Concat-free C2f: every branch writes its channel slice of one [.., (2+n)c] buffer."""
+        c, n = mod.c, len(mod.m)
+        cat = self.p.new(x.N, x.H, x.W, (2 + n) * c, self.code)
+        self.convblock(x, mod.cv1, cat.slice(0, 2 * c), name + ".cv1")
+        prev = cat.slice(c, c)
+        for i, b in enumerate(mod.m):
+            if b.add:
+                raise NotImplementedError("Bottleneck shortcut is never enabled by the reference model")
+            t = self.convblock(prev, b.cv1, None, f"{name}.m.{i}.cv1")
+            dst = cat.slice((2 + i) * c, c)
+            self.convblock(t, b.cv2, dst, f"{name}.m.{i}.cv2")
+            self.p.release(t)
+            prev = dst
+        y = self.convblock(cat, mod.cv2, None, name + ".cv2")
+        self.p.release(cat)
+        return y
+
+    def dw_pointwise(self, x: Act, mod: DepthwiseConvBlock, name=""):
+        """DepthwiseConvBlock (k=1): per-channel scale folded into the pointwise weight, BN folded, ELU."""
+        self._need_eval(mod.bn, name)
+        dw = mod.depthwise.weight.detach().float().reshape(1, -1)
+        pw = mod.pointwise.weight.detach().float().reshape(mod.pointwise.out_channels, -1) * dw
+        scale, shift = _bn_fold(mod.bn)
+        y = self.p.new(x.N, x.H, x.W, pw.shape[0], self.code)
+        self.p.conv(x, self.W(pw), y, scale=self.F(scale), shift=self.F(shift), act=L.ACT_ELU, name=name)
+        return y
+
+    # -- backbone (main_model.py:33-38) --
+    def backbone(self):
+        bb = self.m.backbone
+        body = bb.body
+        N, _, H, W = self.x.shape
+        a = self.p.new(N, H // 4, W // 4, DIMS[0], self.code)
+        self.p.stem(self.x, self.F(body.stem_0.weight.detach().reshape(DIMS[0], 48)), self.F(body.stem_0.bias),
+                    self.F(body.stem_1.weight), self.F(body.stem_1.bias), body.stem_1.eps, a, name="backbone.body.stem")
+        feats = []
+        for si in range(4):
+            st = getattr(body, f"stages_{si}")
+            nm = f"backbone.body.stages_{si}"
+            if si > 0:
+                ln, cv = st.downsample[0], st.downsample[1]
+                t = self.p.new(a.N, a.H, a.W, a.C, self.code)
+                self.p.layernorm(a, self.F(ln.weight), self.F(ln.bias), ln.eps, t, name=nm + ".downsample.0")
+                nxt = self.p.new(a.N, a.H // 2, a.W // 2, cv.out_channels, self.code)
+                self.conv_plain(t, cv, nxt, name=nm + ".downsample.1")
+                self.p.release(t)
+                if si == 1:          # stage-0 output is not a returned feature
+                    self.p.release(a)
+                a = nxt
+            d = a.C
+            for bi, blk in enumerate(st.blocks):
+                bn_ = f"{nm}.blocks.{bi}"
+                t = self.p.new(a.N, a.H, a.W, d, self.code)
+                self.p.dwconv(a, self.F(blk.conv_dw.weight.detach().reshape(d, 49).t()), t, 7, bias=self.F(blk.conv_dw.bias),
+                              lnw=self.F(blk.norm.weight), lnb=self.F(blk.norm.bias), eps=blk.norm.eps, name=bn_ + ".conv_dw+norm")
+                h = self.p.new(a.N, a.H, a.W, 4 * d, self.code)
+                self.p.conv(t, self.W(blk.mlp.fc1.weight), h, shift=self.F(blk.mlp.fc1.bias), act=L.ACT_GELU, name=bn_ + ".mlp.fc1")
+                self.p.release(t)
+                o = self.p.new(a.N, a.H, a.W, d, self.code)
+                g = blk.gamma.detach().float()
+                self.p.conv(h, self.W(blk.mlp.fc2.weight), o, scale=self.F(g), shift=self.F(g * blk.mlp.fc2.bias.detach().float()),
+                            res=a, name=bn_ + ".mlp.fc2")
+                self.p.release(h)
+                self.p.release(a)    # block input: stem / downsample / previous block output, never a feature
+                a = o
+            if si >= 1:
+                feats.append(a)      # stage outputs 1..3 stay live until the adaptors have read them
+        c3 = self.c2f(feats[0], bb.c2f_p3, "backbone.c2f_p3")
+        c4 = self.c2f(feats[1], bb.c2f_p4, "backbone.c2f_p4")
+        c5 = self.c2f(feats[2], bb.c2f_p5, "backbone.c2f_p5")
+        for f in feats:
+            self.p.release(f)
+        return c3, c4, c5
+
+    # -- neck (main_model.py:198-243, 275-296) --
+    @staticmethod
+    def _norm_w(w, eps):
+        w = torch.nn.functional.elu(w.detach().float().cpu())
+        return w / (w.sum(dim=0, keepdim=True) + eps)
+
+    def neck(self, c3, c4, c5):
+        nk = self.m.neck
+        p3 = self.convblock(c3, nk.p3_proj, None, "neck.p3_proj")
+        p4 = self.convblock(c4, nk.p4_proj, None, "neck.p4_proj")
+        p5 = self.convblock(c5, nk.p5_proj, None, "neck.p5_proj")
+        for t in (c3, c4, c5):
+            self.p.release(t)
+        for ui, u in enumerate(nk.bifpn_units):
+            nm = f"neck.bifpn_units.{ui}"
+            a, b = self._norm_w(u.w1, u.eps), self._norm_w(u.w2, u.eps)
+
+            def node(inputs, weights, modes, like: Act, conv, cf, tag):
+                s = self.p.new(like.N, like.H, like.W, like.C, self.code)
+                self.p.fuse(inputs, [float(v) for v in weights], modes, s, name=f"{nm}.{tag}.fuse")
+                d = self.dw_pointwise(s, conv, f"{nm}.{tag}_conv")
+                self.p.release(s)
+                o = self.c2f(d, cf, f"{nm}.{tag}_cf")
+                self.p.release(d)
+                return o
+
+            p4_td = node([p4, p5], [a[0, 0], a[1, 0]], [L.RES_ID, L.RES_UP_BILINEAR], p4, u.p4_td_conv, u.p4_td_cf, "p4_td")
+            p3_td = node([p3, p4_td], [a[0, 1], a[1, 1]], [L.RES_ID, L.RES_UP_BILINEAR], p3, u.p3_td_conv, u.p3_td_cf, "p3_td")
+            p4_out = node([p4, p4_td, p3_td], [b[0, 0], b[1, 0], b[2, 0]], [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN], p4,
+                          u.p4_out_conv, u.p4_out_cf, "p4_out")
+            p5_out = node([p5, p5, p4_out], [b[0, 1], b[1, 1], b[2, 1]], [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN], p5,
+                          u.p5_out_conv, u.p5_out_cf, "p5_out")
+            for t in (p3, p4, p5, p4_td):
+                self.p.release(t)
+            p3, p4, p5 = p3_td, p4_out, p5_out
+        return p3, p4, p5
+
+    # -- heads [ultralytics] --
+    def f32_out(self, N, H, W, Cc) -> Act:
+        return Act.of(torch.empty((N, H, W, Cc), dtype=torch.float32, device=self.x.device))
+
+    def det_branch(self, feats, head: Detect, tag):
+        """cv2 (box, 4*reg_max ch) and cv3 (cls, nc ch) write side by side into one [N,h,w,no] fp32 map
+        (the `torch.cat((cv2_i, cv3_i), 1)` of Detect.forward without the copy)."""
+        maps = []
+        for i, f in enumerate(feats):
+            full = self.f32_out(f.N, f.H, f.W, head.no)
+            s = head.cv2[i]
+            t1 = self.convblock(f, s[0], None, f"{tag}.cv2.{i}.0")
+            t2 = self.convblock(t1, s[1], None, f"{tag}.cv2.{i}.1")
+            self.p.release(t1)
+            self.conv_plain(t2, s[2], full.slice(0, 4 * head.reg_max), f"{tag}.cv2.{i}.2")
+            self.p.release(t2)
+            s = head.cv3[i]
+            d1 = self.dwblock(f, s[0][0], f"{tag}.cv3.{i}.0.0")
+            t1 = self.convblock(d1, s[0][1], None, f"{tag}.cv3.{i}.0.1")
+            self.p.release(d1)
+            d2 = self.dwblock(t1, s[1][0], f"{tag}.cv3.{i}.1.0")
+            self.p.release(t1)
+            t2 = self.convblock(d2, s[1][1], None, f"{tag}.cv3.{i}.1.1")
+            self.p.release(d2)
+            self.conv_plain(t2, s[2], full.slice(4 * head.reg_max, head.nc), f"{tag}.cv3.{i}.2")
+            self.p.release(t2)
+            maps.append(full)
+        return maps
+
+    def seg_extras(self, feats, head: Segment):
+        """Mask coefficients (cv4, all levels into one [N,A,nm] buffer) and prototypes (Proto on P3)."""
+        N = feats[0].N
+        A = sum(f.H * f.W for f in feats)
+        mc = torch.empty((N, A, head.nm), dtype=torch.float32, device=self.x.device)
+        off = 0
+        for i, f in enumerate(feats):
+            s = head.cv4[i]
+            t1 = self.convblock(f, s[0], None, f"segment.cv4.{i}.0")
+            t2 = self.convblock(t1, s[1], None, f"segment.cv4.{i}.1")
+            self.p.release(t1)
+            lvl = Act(mc, off * head.nm, N, f.H, f.W, head.nm, head.nm, A * head.nm)
+            self.conv_plain(t2, s[2], lvl, f"segment.cv4.{i}.2")
+            self.p.release(t2)
+            off += f.H * f.W
+        pr, f = head.proto, feats[0]
+        t1 = self.convblock(f, pr.cv1, None, "segment.proto.cv1")
+        up = self.p.new(f.N, 2 * f.H, 2 * f.W, pr.upsample.out_channels, self.code)
+        wt = pr.upsample.weight.detach()  # [Cin, Cout, 2, 2] -> GEMM rows (dy*2+dx)*Cout + co
+        self.p.conv(t1, self.W(wt.permute(2, 3, 1, 0).reshape(4 * wt.shape[1], wt.shape[0])), up,
+                    shift=self.F(pr.upsample.bias.detach().repeat(4)), out_mode=L.OUT_CONVT2X2, name="segment.proto.upsample")
+        self.p.release(t1)
+        t2 = self.convblock(up, pr.cv2, None, "segment.proto.cv2")
+        self.p.release(up)
+        protos = self.f32_out(f.N, 2 * f.H, 2 * f.W, head.nm)
+        self.convblock(t2, pr.cv3, protos, "segment.proto.cv3")
+        self.p.release(t2)
+        return mc, protos
+
+    def cls_head(self, n5: Act):
+        logits = torch.empty((n5.N, self.m.cls_fc.out_features), dtype=torch.float32, device=self.x.device)
+        self.p.gap_fc(n5, self.F(self.m.cls_fc.weight), self.F(self.m.cls_fc.bias), logits, name="cls_pool+cls_fc")
+        return logits
+
+
+class _Compiled:
+    """One lowered forward: the plan plus the tensors it writes (plan-owned, overwritten every run)."""
+
+    def __init__(self, plan, x_static, det_maps, seg_maps, mc, protos, logits, sig):
+        self.plan, self.x = plan, x_static
+        self.det_maps, self.seg_maps, self.mc, self.protos, self.logits = det_maps, seg_maps, mc, protos, logits
+        self.sig = sig
+
+
+class _Base(nn.Module):
+    """Shared machinery of the two variants: dtype policy, plan cache, forward plumbing."""
+
+    compute_dtype = torch.float32  # torch.float32 = exact-fp32 MFMA (parity); torch.bfloat16 = throughput
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        code_of(dtype)
+        self.compute_dtype = dtype
+        return self
+
+    def _weights_sig(self):
+        return (sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
+                tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)))
+
+    def _heads(self):
+        raise NotImplementedError
+
+    def compile(self, x: torch.Tensor) -> "_Compiled":
+        """Lower the graph for this input's shape/dtype policy (cached until weights or BN modes change)."""
+        if not x.is_cuda:
+            raise RuntimeError("ConvNeXtBiFPNYOLO (HIP) needs CUDA/HIP tensors on an MI355X; there is no CPU path")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected [B,3,S,S] with S a multiple of 32, got {tuple(x.shape)}")
+        key = (tuple(x.shape), self.compute_dtype, x.device.index)
+        sig = self._weights_sig()
+        cache = self.__dict__.setdefault("_plans", {})
+        c = cache.get(key)
+        if c is not None and c.sig == sig:
+            return c
+        with torch.no_grad():
+            xs = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+            lo = _Lowering(self, xs, code_of(self.compute_dtype))
+            c3, c4, c5 = lo.backbone()
+            n3, n4, n5 = lo.neck(c3, c4, c5)
+            feats = [n3, n4, n5]
+            det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
+            seg_maps = lo.det_branch(feats, self.segment, "segment")
+            mc, protos = lo.seg_extras(feats, self.segment)
+            logits = lo.cls_head(n5)
+        c = _Compiled(lo.p, xs, det_maps, seg_maps, mc, protos, logits, sig)
+        cache[key] = c
+        return c
+
+    def _run(self, x: torch.Tensor) -> "_Compiled":
+        c = self.compile(x)
+        c.x.copy_(x)  # boundary: caller's image batch (any float dtype / layout) -> the plan's NCHW fp32 input
+        c.plan.run()
+        return c
+
+    # decoded `[B, 4+nc(+nm), A]` tensor of Detect/Segment eval (ultralytics `_inference`), from raw maps
+    def _preds_cat(self, maps: List[Act], head: Detect, mc: torch.Tensor = None):
+        from . import postprocess as pp
+        return pp.detect_inference(maps, head, mc)
+
+
+class ConvNeXtBiFPNYOLO(_Base):
+    """Canonical variant, `/root/reference/src/main_model.py:300-393`."""
+
+    def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32, bifpn_feature_size: int = 256,
+                 bifpn_num_layers: int = 2, pretrained_backbone: bool = True):
+        super().__init__()
+        L.load()  # fail loudly at construction if the HIP library is absent
+        self.backbone = ConvNeXtTiny(pretrained=pretrained_backbone)
+        self.neck = BiFPN(size=[256, 384, 512], feature_size=bifpn_feature_size, num_layers=bifpn_num_layers)
+        ch = [bifpn_feature_size] * 3
+        self.detect = Detect(nc=nc_det, ch=ch)
+        self.segment = Segment(nc=nc_det, nm=proto_ch, npr=bifpn_feature_size, ch=ch)
+        self.cls_pool = nn.AdaptiveAvgPool2d(1)
+        self.cls_fc = nn.Linear(bifpn_feature_size, nc_img)
+        self.nc_det, self.nc_img, self.proto_ch = nc_det, nc_img, proto_ch
+
+    def forward(self, x, mode: str = "train"):
+        det_flag, seg_flag = self.detect.training, self.segment.training
+        try:
+            if mode == "train":      # main_model.py:357-365
+                self.detect.train()
+                self.segment.train()
+                c = self._run(x)
+                det = [m.nchw().clone() for m in c.det_maps]
+                seg = [m.nchw().clone() for m in c.seg_maps]
+                return det, (seg, c.mc.permute(0, 2, 1).clone(), c.protos.nchw().clone()), c.logits.clone()
+            if mode == "infer":      # main_model.py:367-386
+                self.detect.eval()
+                self.segment.eval()
+                c = self._run(x)
+                det_feats = [m.nchw().clone() for m in c.det_maps]
+                seg_feats = [m.nchw().clone() for m in c.seg_maps]
+                mc = c.mc.permute(0, 2, 1).clone()
+                logits = c.logits.clone()
+                return {
+                    "detect_features": det_feats,
+                    "detect_preds_cat": self._preds_cat(c.det_maps, self.detect),
+                    "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
+                    "segment_preds_cat": self._preds_cat(c.seg_maps, self.segment, c.mc),
+                    "img_cls_logits": logits,
+                    "img_cls_probs": logits.softmax(dim=1),
+                }
+            raise ValueError(f"Unknown mode for ConvNeXtBiFPNYOLO.forward: {mode}. Expected 'train' or 'infer'.")
+        finally:  # top-level flags only, as the reference does (main_model.py:391-393)
+            self.detect.training = det_flag
+            self.segment.training = seg_flag
+
+
+class ConvNeXtBiFPNYOLOv2(_Base):
+    """Segment-only variant, `/root/reference/src/main_modelv2.py:300-385`."""
+
+    def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32, bifpn_feature_size: int = 256,
+                 bifpn_num_layers: int = 2, pretrained_backbone: bool = True):
+        super().__init__()
+        L.load()
+        self.backbone = ConvNeXtTiny(pretrained=pretrained_backbone)
+        self.neck = BiFPN(size=[256, 384, 512], feature_size=bifpn_feature_size, num_layers=bifpn_num_layers)
+        ch = [bifpn_feature_size] * 3
+        self.segment = Segment(nc=nc_det, nm=proto_ch, npr=bifpn_feature_size, ch=ch)
+        self.cls_pool = nn.AdaptiveAvgPool2d(1)
+        self.cls_fc = nn.Linear(bifpn_feature_size, nc_img)
+        self.nc_det, self.nc_img, self.proto_ch = nc_det, nc_img, proto_ch
+
+    def forward(self, x, mode: str = "train"):
+        seg_flag = self.segment.training
+        try:
+            if mode == "train":      # main_modelv2.py:353-360
+                self.segment.train()
+                c = self._run(x)
+                seg = [m.nchw().clone() for m in c.seg_maps]
+                return (seg, c.mc.permute(0, 2, 1).clone(), c.protos.nchw().clone()), c.logits.clone()
+            if mode == "infer":      # main_modelv2.py:362-378
+                self.segment.eval()
+                c = self._run(x)
+                seg_feats = [m.nchw().clone() for m in c.seg_maps]
+                mc = c.mc.permute(0, 2, 1).clone()
+                seg_cat = self._preds_cat(c.seg_maps, self.segment, c.mc)
+                logits = c.logits.clone()
+                return {
+                    "detect_preds_cat": seg_cat[:, : 4 + self.nc_det],
+                    "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
+                    "segment_preds_cat": seg_cat,
+                    "img_cls_logits": logits,
+                    "img_cls_probs": logits.softmax(dim=1),
+                }
+            raise ValueError(f"Unknown mode for ConvNeXtBiFPNYOLO.forward: {mode}. Expected 'train' or 'infer'.")
+        finally:
+            self.segment.training = seg_flag
+
+
+@torch.no_grad()
+def init_synthetic_(model: nn.Module, seed: int = 0) -> nn.Module:
+    """Seeded synthetic weights for benchmarks (no checkpoints offline): torch default inits as built,
+    BatchNorm statistics / affine randomised, layer-scale gamma ~ U(.05,.15), BiFPN w1/w2 = 1."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+            m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    for name, p in model.named_parameters():
+        if name.endswith(".gamma"):
+            p.copy_((torch.rand(p.shape, generator=g) + 0.5) * 0.1)
+        elif name.endswith(".w1") or name.endswith(".w2"):
+            p.fill_(1.0)
+    return model

@@ -1,0 +1,255 @@
+"""GPU parity of each HIP kernel against the CPU oracle / plain torch fp32 on the same seeded inputs.
+Everything goes through the C ABI (ctypes -> libmtbt_hip.so).  fp32 kernels: <= 1e-3 absolute
+(north_star tolerance; observed ~1e-5); bf16 kernels: relative-to-max tolerance stated per test."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from multitask_bonetumor_yolo_amd import _lib as L
+    from multitask_bonetumor_yolo_amd.engine import Act, Plan
+
+DEV = "cuda:0"
+TOL32 = 1e-3
+
+
+def nhwc(t):  # [N,C,H,W] cpu -> dense NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def back(t):  # NHWC cuda -> NCHW cpu fp32
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def run(plan):
+    plan.run()
+    torch.cuda.synchronize()
+
+
+ACTS = {0: lambda v: v, 1: F.silu, 2: F.elu, 3: F.gelu}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    # (N, H, W, C, K, k, stride, pad, act, residual, tile_hint)
+    (2, 12, 12, 64, 64, 3, 1, 1, 1, False, 0),
+    (1, 20, 20, 128, 128, 3, 1, 1, 1, False, 0),
+    (2, 9, 7, 96, 384, 1, 1, 0, 3, False, 0),        # ConvNeXt fc1 (+GELU), ragged pixel tile, TC=128
+    (2, 9, 7, 384, 96, 1, 1, 0, 0, True, 0),         # ConvNeXt fc2 + layer-scale residual, TC=96
+    (1, 16, 16, 96, 192, 2, 2, 0, 0, False, 0),      # downsample 2x2/2
+    (1, 8, 8, 256, 2, 1, 1, 0, 0, False, 0),         # cls conv, K=2 (scalar epilogue)
+    (1, 10, 10, 64, 32, 1, 1, 0, 1, False, 0),
+    (3, 16, 16, 256, 256, 3, 1, 1, 1, False, (128 << 16) | 128),
+    (3, 16, 16, 256, 256, 3, 1, 1, 2, False, (128 << 16) | 64),
+    (1, 16, 16, 192, 192, 3, 1, 1, 1, False, (96 << 16) | 128),
+    (1, 16, 16, 192, 192, 3, 1, 1, 1, False, (96 << 16) | 64),
+    (1, 16, 16, 64, 64, 3, 1, 1, 1, False, (64 << 16) | 128),
+    (1, 16, 16, 64, 64, 3, 1, 1, 1, False, (64 << 16) | 64),
+    (1, 16, 16, 64, 48, 3, 1, 1, 1, False, (32 << 16) | 128),
+    (1, 16, 16, 64, 48, 3, 1, 1, 1, False, (32 << 16) | 64),
+    (1, 1, 1, 32, 16, 1, 1, 0, 0, False, 0),         # single pixel
+])
+def test_conv_igemm(dtype, cfg):
+    N, H, W, Cin, K, k, st, pad, act, use_res, hint = cfg
+    if dtype == torch.float32 and Cin % 16:
+        pytest.skip("C % 16")
+    if dtype == torch.bfloat16 and Cin % 32:
+        pytest.skip("C % 32")
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(K, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(K, generator=g) + 0.5
+    shift = torch.randn(K, generator=g) * 0.1
+    Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, K, Ho, Wo, generator=g) if use_res else None
+    if dtype == torch.bfloat16:  # the kernel sees bf16-rounded operands; give the reference the same
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+        res = res.bfloat16().float() if use_res else None
+    ref = ACTS[act](F.conv2d(x, w, None, st, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    if use_res:
+        ref = ref + res
+    p = Plan(torch.device(DEV))
+    xa = Act.of(nhwc(x).to(dtype))
+    wp = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().to(DEV, dtype)
+    ya = Act.of(torch.zeros(N, Ho, Wo, K, dtype=dtype, device=DEV))
+    ra = Act.of(nhwc(res).to(dtype)) if use_res else None
+    p.conv(xa, wp, ya, R=k, S=k, stride=st, pad=pad, scale=scale.to(DEV), shift=shift.to(DEV), act=act, res=ra, tile_hint=hint)
+    run(p)
+    out = back(ya.buf)
+    if dtype == torch.float32:
+        assert (out - ref).abs().max().item() < TOL32
+    else:  # bf16 output rounding: 2^-8 relative
+        assert ((out - ref).abs() / (ref.abs() + 1.0)).max().item() < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_channel_slices_and_f32_out(dtype):
+    """Concat-free C2f addressing: read a channel slice, write a channel slice of a wider buffer; fp32 output."""
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 2, 10, 10
+    xin = torch.randn(N, 128, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    if dtype == torch.bfloat16:
+        xin, w = xin.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(xin[:, 64:128], w, None, 1, 1)
+    p = Plan(torch.device(DEV))
+    xa = Act.of(nhwc(xin).to(dtype)).slice(64, 64)
+    ybuf = torch.full((N, H, W, 66), 7.0, dtype=torch.float32, device=DEV)
+    ya = Act.of(ybuf).slice(2, 64)   # misaligned for vector stores -> scalar epilogue
+    p.conv(xa, w.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(DEV, dtype), ya, R=3, S=3, pad=1)
+    run(p)
+    out = back(ybuf)
+    assert torch.all(out[:, :2] == 7.0)
+    tol = TOL32 if dtype == torch.float32 else 2e-2
+    assert (out[:, 2:66] - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose_2x2(dtype):
+    g = torch.Generator().manual_seed(4)
+    N, H, W, Cin, Cout = 2, 6, 5, 64, 32
+    x = torch.randn(N, Cin, H, W, generator=g)
+    wt = torch.randn(Cin, Cout, 2, 2, generator=g) / 8
+    b = torch.randn(Cout, generator=g)
+    if dtype == torch.bfloat16:
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+    ref = F.conv_transpose2d(x, wt, b, 2)
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(N, 2 * H, 2 * W, Cout, dtype=dtype, device=DEV))
+    p.conv(Act.of(nhwc(x).to(dtype)), wt.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).contiguous().to(DEV, dtype), ya,
+           shift=b.repeat(4).to(DEV), out_mode=L.OUT_CONVT2X2)
+    run(p)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+def test_conv_rejects_bad_args():
+    lib = L.load()
+    a = L.ConvArgs()
+    assert lib.mtbt_conv2d_nhwc(C.byref(a), None) == -1
+    assert lib.mtbt_conv2d_nhwc(None, None) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem(dtype):
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 32, 64, generator=g)
+    w = torch.randn(96, 3, 4, 4, generator=g) / 7
+    b = torch.randn(96, generator=g) * 0.1
+    lw, lb = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g) * 0.1
+    y = F.conv2d(x, w, b, 4)
+    ref = F.layer_norm(y.permute(0, 2, 3, 1), (96,), lw, lb, 1e-6).permute(0, 3, 1, 2)
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(2, 8, 16, 96, dtype=dtype, device=DEV))
+    p.stem(x.to(DEV), w.reshape(96, 48).contiguous().to(DEV), b.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, ya)
+    run(p)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 96, 9, 11), (1, 192, 8, 8), (1, 768, 5, 6), (1, 384, 4, 4)])
+def test_dwconv7_layernorm(dtype, shape):
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    w = torch.randn(Cc, 1, 7, 7, generator=g) / 7
+    b = torch.randn(Cc, generator=g) * 0.1
+    lw, lb = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    y = F.conv2d(x, w, b, 1, 3, groups=Cc)
+    ref = F.layer_norm(y.permute(0, 2, 3, 1), (Cc,), lw, lb, 1e-6).permute(0, 3, 1, 2)
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(N, H, W, Cc, dtype=dtype, device=DEV))
+    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 49).t().contiguous().to(DEV), ya, 7, bias=b.to(DEV), lnw=lw.to(DEV),
+             lnb=lb.to(DEV), eps=1e-6)
+    run(p)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv3_affine_silu(dtype):
+    g = torch.Generator().manual_seed(7)
+    N, Cc, H, W = 2, 256, 7, 10
+    x = torch.randn(N, Cc, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    w = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x, w, None, 1, 1, groups=Cc) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(N, H, W, Cc, dtype=dtype, device=DEV))
+    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 9).t().contiguous().to(DEV), ya, 3, scale=sc.to(DEV), shift=sh.to(DEV), act=1)
+    run(p)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc", [96, 192, 768])
+def test_layernorm(dtype, Cc):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, Cc, 5, 7, generator=g) * 2 + 0.5
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    lw, lb = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    ref = F.layer_norm(x.permute(0, 2, 3, 1), (Cc,), lw, lb, 1e-6).permute(0, 3, 1, 2)
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(2, 5, 7, Cc, dtype=dtype, device=DEV))
+    p.layernorm(Act.of(nhwc(x).to(dtype)), lw.to(DEV), lb.to(DEV), 1e-6, ya)
+    run(p)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bifpn_fuse_modes(dtype):
+    g = torch.Generator().manual_seed(9)
+    Cc = 64
+    mid = torch.randn(2, Cc, 8, 6, generator=g)
+    small = torch.randn(2, Cc, 4, 3, generator=g)
+    big = torch.randn(2, Cc, 16, 12, generator=g)
+    if dtype == torch.bfloat16:
+        mid, small, big = (t.bfloat16().float() for t in (mid, small, big))
+    w = [0.3, 0.45, 0.25]
+    cases = [
+        ([mid, small], [0, 1], w[0] * mid + w[1] * F.interpolate(small, scale_factor=2, mode="bilinear")),
+        ([mid, mid, big], [0, 0, 2], w[0] * mid + w[1] * mid + w[2] * F.interpolate(big, scale_factor=0.5, mode="bilinear")),
+        ([mid, small], [0, 3], w[0] * mid + w[1] * F.interpolate(small, scale_factor=2, mode="nearest")),
+        ([mid, big], [0, 4], w[0] * mid + w[1] * F.max_pool2d(big, 2)),
+    ]
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    for ins, modes, ref in cases:
+        p = Plan(torch.device(DEV))
+        ya = Act.of(torch.zeros(2, 8, 6, Cc, dtype=dtype, device=DEV))
+        p.fuse([Act.of(nhwc(t).to(dtype)) for t in ins], w[:len(ins)], modes, ya)
+        run(p)
+        assert (back(ya.buf) - ref).abs().max().item() < tol, modes
+    # src/model.py:33-36 WeightedAdd bug: sum(w_i + f_i)
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(2, 8, 6, Cc, dtype=dtype, device=DEV))
+    p.fuse([Act.of(nhwc(mid).to(dtype)), Act.of(nhwc(small).to(dtype))], w[:2], [0, 3], ya, bug=True)
+    run(p)
+    ref = (w[0] + mid) + (w[1] + F.interpolate(small, scale_factor=2, mode="nearest"))
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gap_fc(dtype):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(3, 256, 5, 4, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    w, b = torch.randn(2, 256, generator=g) / 16, torch.randn(2, generator=g)
+    ref = F.linear(x.mean((2, 3)), w, b)
+    p = Plan(torch.device(DEV))
+    y = torch.zeros(3, 2, device=DEV)
+    p.gap_fc(Act.of(nhwc(x).to(dtype)), w.to(DEV), b.to(DEV), y)
+    run(p)
+    assert (y.cpu() - ref).abs().max().item() < 1e-4

@@ -1,0 +1,158 @@
+"""End-to-end parity of the drop-in module against the CPU oracle with the SAME state_dict and inputs.
+fp32 mode (exact-fp32 MFMA): logits / raw maps / protos within 1e-3 (north_star).  bf16 mode: relative error
+bound stated below (bf16 storage of ~100 layers of activations)."""
+import pytest
+import torch
+
+from oracle import postprocess as opp
+from oracle.model import ConvNeXtBiFPNYOLO as OracleModel
+from oracle.model import ConvNeXtBiFPNYOLOv2 as OracleModelV2
+from oracle.model import randomize_
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv2, postprocess as pp
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pair():
+    torch.manual_seed(0)
+    ora = randomize_(OracleModel(2, 2, pretrained_backbone=False)).eval()
+    hip = ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)
+    missing, unexpected = hip.load_state_dict(ora.state_dict(), strict=True)
+    assert not missing and not unexpected
+    return ora, hip.to(DEV).eval()
+
+
+def maxdiff(a, b):
+    return (a.float().cpu() - b).abs().max().item()
+
+
+def relerr(a, b):
+    return ((a.float().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 160)])
+def test_infer_fp32_parity(pair, B, S):
+    ora, hip = pair
+    hip.set_compute_dtype(torch.float32)
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(S))
+    with torch.no_grad():
+        ref = ora(x, "infer")
+        out = hip(x.to(DEV), "infer")
+    torch.cuda.synchronize()
+    assert set(out) == set(ref)
+    for o, r in zip(out["detect_features"], ref["detect_features"]):
+        assert o.shape == r.shape and maxdiff(o, r) < 1e-3
+    seg_feats, mc, protos = out["segment_protos"]
+    rseg_feats, rmc, rprotos = ref["segment_protos"]
+    for o, r in zip(seg_feats, rseg_feats):
+        assert o.shape == r.shape and maxdiff(o, r) < 1e-3
+    assert mc.shape == rmc.shape and maxdiff(mc, rmc) < 1e-3
+    assert protos.shape == rprotos.shape and maxdiff(protos, rprotos) < 1e-3
+    assert maxdiff(out["img_cls_logits"], ref["img_cls_logits"]) < 1e-3
+    assert maxdiff(out["img_cls_probs"], ref["img_cls_probs"]) < 1e-3
+    # Detect eval output with the reference's never-set stride (zeros): boxes are exactly 0
+    for key in ("detect_preds_cat", "segment_preds_cat"):
+        assert out[key].shape == ref[key].shape
+        assert maxdiff(out[key], ref[key]) < 1e-3
+    assert torch.all(out["detect_preds_cat"][:, :4] == 0)
+
+
+def test_infer_with_strides_set(pair):
+    ora, hip = pair
+    hip.set_compute_dtype(torch.float32)
+    x = torch.rand(1, 3, 96, 96, generator=torch.Generator().manual_seed(5))
+    st = torch.tensor([8.0, 16.0, 32.0])
+    old = (ora.detect.stride, ora.segment.stride, hip.detect.stride, hip.segment.stride)
+    try:
+        ora.detect.stride = ora.segment.stride = st
+        hip.detect.stride = hip.segment.stride = st
+        with torch.no_grad():
+            ref = ora(x, "infer")
+            out = hip(x.to(DEV), "infer")
+        torch.cuda.synchronize()
+        for key in ("detect_preds_cat", "segment_preds_cat"):
+            assert torch.allclose(out[key].cpu(), ref[key], rtol=1e-4, atol=2e-3)
+    finally:
+        ora.detect.stride, ora.segment.stride, hip.detect.stride, hip.segment.stride = old
+
+
+def test_infer_bf16_close(pair):
+    ora, hip = pair
+    hip.set_compute_dtype(torch.bfloat16)
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = ora(x, "infer")
+        out = hip(x.to(DEV), "infer")
+    torch.cuda.synchronize()
+    hip.set_compute_dtype(torch.float32)
+    # bf16 activations/weights (8 mantissa bits) through ~100 layers: relative L2 error bound 5e-2
+    for o, r in zip(out["detect_features"], ref["detect_features"]):
+        assert relerr(o, r) < 5e-2
+    _, mc, protos = out["segment_protos"]
+    assert relerr(mc, ref["segment_protos"][1]) < 5e-2
+    assert relerr(protos, ref["segment_protos"][2]) < 5e-2
+    assert maxdiff(out["img_cls_probs"], ref["img_cls_probs"]) < 3e-2
+
+
+def test_postprocess_pipeline_on_model_outputs(pair):
+    """decode -> NMS -> masks on the HIP model's outputs equals the oracle post-process run on the same outputs
+    (kept indices bit-exact), and equals the all-CPU pipeline up to boxes that sit on a decision boundary."""
+    ora, hip = pair
+    hip.set_compute_dtype(torch.float32)
+    S = 160
+    x = torch.rand(2, 3, S, S, generator=torch.Generator().manual_seed(21))
+    with torch.no_grad():
+        out = hip(x.to(DEV), "infer")
+    seg_feats, mc, protos = out["segment_protos"]
+    res = pp.detect_and_segment(out["detect_features"], mc, protos, S)
+    torch.cuda.synchronize()
+    maps_cpu = [m.float().cpu() for m in out["detect_features"]]
+    boxes, scores, _ = opp.decode_levels(maps_cpu, S)
+    d = pp.decode_boxes(out["detect_features"], S)
+    for b in range(2):
+        # oracle NMS on the GPU-decoded boxes: identical kept set
+        bs, bl = d["scores"][b].cpu().max(dim=1)
+        k, anchors, kb, ks, kl = opp.filter_and_nms(d["boxes"][b].cpu(), d["scores"][b].cpu(), S)
+        n = int(res["counts"][b])
+        assert n == len(k)
+        assert torch.equal(res["keep_idx"][b, :n].cpu(), k)
+        assert torch.equal(res["boxes"][b, :n].cpu(), kb)
+        # masks of the kept boxes
+        coeffs = mc[b].cpu()[:, anchors].t()
+        ref_logits, ref_masks = opp.assemble_masks(coeffs, protos[b].cpu(), (S, S))
+        diff = res["masks"][b, :n].cpu() != ref_masks
+        assert torch.all(ref_logits[diff].abs() < 1e-4)
+        # decode parity against the CPU decode of the same maps
+        assert torch.allclose(d["boxes"][b].cpu(), boxes[b], rtol=1e-5, atol=1e-3)
+
+
+def test_v2_variant_layout():
+    torch.manual_seed(1)
+    ora = randomize_(OracleModelV2(2, 3, pretrained_backbone=False)).eval()
+    hip = ConvNeXtBiFPNYOLOv2(2, 3, pretrained_backbone=False)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.to(DEV).eval()
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = ora(x, "infer")
+        out = hip(x.to(DEV), "infer")
+    torch.cuda.synchronize()
+    assert set(out) == set(ref)
+    assert out["detect_preds_cat"].shape == ref["detect_preds_cat"].shape
+    assert maxdiff(out["segment_preds_cat"], ref["segment_preds_cat"]) < 1e-3
+    assert maxdiff(out["img_cls_logits"], ref["img_cls_logits"]) < 1e-3
+
+
+def test_errors(pair):
+    _, hip = pair
+    with pytest.raises(ValueError):
+        hip(torch.rand(1, 3, 64, 64, device=DEV), "eval")
+    with pytest.raises(ValueError):
+        hip(torch.rand(1, 3, 65, 64, device=DEV), "infer")
+    with pytest.raises(RuntimeError):
+        hip(torch.rand(1, 3, 64, 64), "infer")  # CPU tensor: no CPU path
