@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/s of the 640x640 multitask forward (det + seg + cls) in bf16 plus
+the decode / NMS / mask post-process, batch 16 per GPU (BASELINE.json configs[1]), synthetic inputs
+resident in HBM, random-init weights (no datasets or checkpoints offline).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; images are independent so the batch is sharded with NO data-path collective
+(scaling = weak); ranks only meet at the timing barriers.  Rank 0 prints one JSON line.
+
+Extra objects on that line:
+  roofline      the implicit-GEMM MFMA conv kernel family (99% of the FLOPs): algorithmic FLOPs of its
+                launches / their summed durations, measured with HIP events around every launch in a
+                separate instrumented replay of the same plan (profiles/ holds the rocprofv3 summary).
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference forward) timed on this host's cores on a
+                bounded sample (batch 1, a few iterations): a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 16
+IMG = 640
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def cpu_baseline(seconds_budget=20.0):
+    from oracle import postprocess as opp
+    from oracle.model import ConvNeXtBiFPNYOLO as OracleModel, randomize_
+    torch.manual_seed(0)
+    m = randomize_(OracleModel(2, 2, pretrained_backbone=False)).eval()
+    x = torch.rand(1, 3, IMG, IMG, generator=torch.Generator().manual_seed(0))
+    cores = torch.get_num_threads()
+
+    def one():
+        with torch.no_grad():
+            out = m(x, "infer")
+            feats, mc, protos = out["segment_protos"]
+            boxes, scores, _ = opp.decode_levels(out["detect_features"], IMG)
+            k, anchors, *_ = opp.filter_and_nms(boxes[0], scores[0], IMG)
+            if len(k):
+                opp.assemble_masks(mc[0][:, anchors].t(), protos[0], (IMG, IMG))
+
+    one()
+    t0 = time.time()
+    n = 0
+    while n < 10 and (time.time() - t0 < seconds_budget or n < 2):
+        one()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 forward + decode/NMS/masks, batch 1 x {n} iterations at {IMG}x{IMG}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, init_synthetic_, postprocess as pp
+
+    torch.manual_seed(0)
+    model = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    B = args.batch
+    x = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(rank)).to(dev)  # resident in HBM
+
+    def step():
+        with torch.no_grad():
+            out = model(x, "infer")
+            feats, mc, protos = out["segment_protos"]
+            return pp.detect_and_segment(out["detect_features"], mc, protos, IMG)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: instrumented replay of the same plan ----
+        c = model.compile(x)
+        reps = 3
+        acc = None
+        for _ in range(reps):
+            ms = c.plan.run_timed()
+            acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
+        ms = [a / reps for a in acc]
+        conv = [(l, t) for l, t in zip(c.plan.launches, ms) if l.fn is c.plan.lib.mtbt_conv2d_nhwc]
+        conv_flops = sum(l.flops for l, _ in conv)
+        conv_ms = sum(t for _, t in conv)
+        all_ms = sum(ms)
+        if args.kernel_table:
+            for l, t in sorted(zip(c.plan.launches, ms), key=lambda p: -p[1])[:40]:
+                tf = l.flops / (t * 1e-3) / 1e12 if t > 0 else 0
+                print(f"{t*1e3:9.1f} us  {tf:7.1f} TF/s  {l.bytes/(t*1e-3)/1e9 if t>0 else 0:8.0f} GB/s  {l.name}", file=sys.stderr)
+            print(f"plan: {len(c.plan.launches)} launches, {all_ms:.3f} ms (conv {conv_ms:.3f} ms, {len(conv)} launches), "
+                  f"pool {c.plan.pool.bytes/2**20:.0f} MiB", file=sys.stderr)
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "launches_per_step": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
+                    "flop_per_launch": round(conv_flops / len(conv)), "conv_ms_per_step": round(conv_ms, 3),
+                    "all_kernels_ms_per_step": round(all_ms, 3)}
+        line = {
+            "metric": "images/sec at 640x640 multitask fwd (det+seg+cls) + decode/NMS/masks",
+            "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch-{B}/GPU {IMG}x{IMG} multitask inference (ConvNeXt-T + C2f-BiFPN + Detect/Segment/cls) "
+                                   f"+ decode + per-image NMS(top-100) + mask assembly; random-init weights",
+                       "batch_per_gpu": B, "img": IMG, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
+                       "kept_boxes_per_image": float(res["counts"].float().mean().item())},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

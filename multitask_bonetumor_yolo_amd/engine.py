@@ -114,6 +114,22 @@ class Plan:
             if rc != 0:
                 L.check(rc, l.name)
 
+    def run_timed(self):
+        """Replay with a HIP event pair around every launch (all on torch's current stream, which is the stream
+        the kernels are launched on).  Returns per-launch milliseconds; slower than run(), for roofline accounting."""
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        evs = []
+        for l in self.launches:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = l.fn(*l.args, s)
+            b.record()
+            if rc != 0:
+                L.check(rc, l.name)
+            evs.append((a, b))
+        torch.cuda.synchronize(self.device)
+        return [a.elapsed_time(b) for a, b in evs]
+
     # ---- helpers ----
     def const(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
         t = t.detach().to(device=self.device, dtype=dtype or t.dtype).contiguous()

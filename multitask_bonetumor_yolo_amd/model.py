@@ -493,7 +493,14 @@ class _Base(nn.Module):
 
     def _run(self, x: torch.Tensor) -> "_Compiled":
         c = self.compile(x)
-        c.x.copy_(x)  # boundary: caller's image batch (any float dtype / layout) -> the plan's NCHW fp32 input
+        stem = c.plan.launches[0]
+        if x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0:
+            src = x            # read the caller's resident NCHW fp32 batch in place
+        else:
+            c.x.copy_(x)       # other dtypes / layouts: one conversion copy into the plan's input buffer
+            src = c.x
+        stem.args = (src.data_ptr(),) + stem.args[1:]
+        stem.keep = (src,) + tuple(stem.keep[1:])
         c.plan.run()
         return c
 
