@@ -39,7 +39,8 @@ def cpu_baseline(seconds_budget=20.0):
     torch.manual_seed(0)
     m = randomize_(OracleModel(2, 2, pretrained_backbone=False)).eval()
     x = torch.rand(1, 3, IMG, IMG, generator=torch.Generator().manual_seed(0))
-    cores = torch.get_num_threads()
+    cores = min(len(os.sched_getaffinity(0)), 32)  # the GPU box shares its host; stay within a sane slice
+    torch.set_num_threads(cores)
 
     def one():
         with torch.no_grad():
@@ -128,6 +129,9 @@ def main():
         conv_ms = sum(t for _, t in conv)
         all_ms = sum(ms)
         if args.kernel_table:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "layer_times.json"), "w") as f:
+                json.dump([{"name": l.name, "us": t * 1e3, "flops": l.flops, "bytes": l.bytes} for l, t in zip(c.plan.launches, ms)], f)
             for l, t in sorted(zip(c.plan.launches, ms), key=lambda p: -p[1])[:40]:
                 tf = l.flops / (t * 1e-3) / 1e12 if t > 0 else 0
                 print(f"{t*1e3:9.1f} us  {tf:7.1f} TF/s  {l.bytes/(t*1e-3)/1e9 if t>0 else 0:8.0f} GB/s  {l.name}", file=sys.stderr)

@@ -96,9 +96,9 @@ int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float* bias, cons
  *   ln_w != NULL : + bias, then LayerNorm over C (ConvNeXt block conv_dw + norm, [timm])
  *   ln_w == NULL : * scale[c] + shift[c], then activation (ultralytics DWConv + BN + SiLU,
  *                  Detect.cv3, main_model.py:324 [ultralytics])
- *   w [k*k][C] f32 (tap-major);  C % 8 == 0, C <= 1024.
+ *   w [k*k][C] (tap-major) in the activation dtype;  C % 8 == 0, C <= 768.
  * ------------------------------------------------------------------------------------------- */
-int mtbt_dwconv_nhwc(const void* x, const float* w, const float* bias, const float* ln_w,
+int mtbt_dwconv_nhwc(const void* x, const void* w, const float* bias, const float* ln_w,
                      const float* ln_b, float ln_eps, const float* scale, const float* shift, int act,
                      void* y, int N, int H, int W, int C, int ksize, int dtype, void* stream);
 

@@ -1,0 +1,19 @@
+// Launch parameters of the implicit-GEMM conv kernel (host <-> device).
+#pragma once
+
+struct ConvP {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* scale;
+  const float* shift;
+  const void* res;
+  long xbs, ybs, rbs;
+  int ldx, ldy, ldr;
+  int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
+  int act, out_mode, out_f32, vec_ok;
+  int y_linear;  // output (and residual) batch stride == Ho*Wo*pixel stride: offset = pix*ld, no division
+  int M;       // N*Ho*Wo (< 2^31)
+  int ctiles;  // ceil(K / TC)
+  int ptiles_per_xcd;  // ceil(ceil(M / TP) / 8)
+};

@@ -1,6 +1,5 @@
 // Bandwidth-bound kernels of the forward path (NHWC, 16-byte accesses, fp32 arithmetic):
-// ConvNeXt stem (4x4/4 conv + LayerNorm2d), depthwise k x k conv with LayerNorm or affine+activation
-// epilogue, LayerNorm over channels, BiFPN weighted fusion with resampling, GAP + Linear, casts.
+// ConvNeXt stem (4x4/4 conv + LayerNorm2d), LayerNorm over channels, BiFPN weighted fusion with resampling, GAP + Linear, casts.
 #include "common.h"
 
 namespace {
@@ -65,121 +64,6 @@ __global__ void stem_kernel(const float* __restrict__ x, const float* __restrict
       for (int c = lane; c < Cout; c += 64) st_elem<OT>(y + gp * Cout + c, (o[c] - mean) * rstd * lnw[c] + lnb[c]);
     }
     __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Depthwise KS x KS, stride 1, pad KS/2.  Thread = (row y, block of XB consecutive x, 8-channel chunk);
-// the chunk index is the fastest thread index so a pixel's channels are read as one contiguous run.
-// Per filter row the thread loads XB+KS-1 input vectors once and slides the taps over them.
-// LN epilogue: per-pixel (mean, M2) partials over 8 channels are combined across the pixel's chunk
-// threads through LDS with the equal-count parallel-variance formula (single pass, no cancellation).
-// ------------------------------------------------------------------------------------------------
-template <typename T, int KS, bool LN>
-__global__ void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                              const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
-                              const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                              T* __restrict__ y, int N, int H, int W, int C, int slots) {
-  constexpr int XB = 4, PAD = KS / 2, SPAN = XB + KS - 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int CH8 = C >> 3;
-  const int tid = threadIdx.x;
-  const int chunk = tid % CH8, slot = tid / CH8;
-  const int XBs = (W + XB - 1) / XB;
-  const long items = (long)N * H * XBs;
-  const long item = (long)blockIdx.x * slots + slot;
-  const bool live = item < items;
-  const long it = live ? item : 0;
-  const int xb = (int)(it % XBs);
-  const long ny = it / XBs;
-  const int yy = (int)(ny % H);
-  const int n = (int)(ny / H);
-  const int x0 = xb * XB;
-  const int c0 = chunk * 8;
-
-  float acc[XB][8];
-#pragma unroll
-  for (int i = 0; i < XB; ++i)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
-
-  if (live) {
-    const T* xn = x + (long)n * H * W * C + c0;
-#pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky) {
-      const int iy = yy + ky - PAD;
-      if ((unsigned)iy >= (unsigned)H) continue;
-      float in[SPAN][8];
-#pragma unroll
-      for (int j = 0; j < SPAN; ++j) {
-        const int ix = x0 + j - PAD;
-        if ((unsigned)ix < (unsigned)W) ld8<T>(xn + ((long)iy * W + ix) * C, in[j]);
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) in[j][e] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        float wv[8];
-        ld8<float>(w + (long)(ky * KS + kx) * C + c0, wv);
-#pragma unroll
-        for (int i = 0; i < XB; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(in[i + kx][e], wv[e], acc[i][e]);
-      }
-    }
-  }
-
-  if constexpr (LN) {
-    float bv[8], gw[8], gb[8];
-    ld8<float>(bias + c0, bv);
-    ld8<float>(lnw + c0, gw);
-    ld8<float>(lnb + c0, gb);
-    float2* red = reinterpret_cast<float2*>(smem);  // [slots][XB][CH8] (mean8, M2_8)
-#pragma unroll
-    for (int i = 0; i < XB; ++i) {
-      float m = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { acc[i][e] += bv[e]; m += acc[i][e]; }
-      m *= 0.125f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = acc[i][e] - m; m2 += d * d; }
-      red[(slot * XB + i) * CH8 + chunk] = make_float2(m, m2);
-    }
-    __syncthreads();
-    if (!live) return;
-    T* yo = y + (((long)n * H + yy) * W) * C + c0;
-#pragma unroll
-    for (int i = 0; i < XB; ++i) {
-      if (x0 + i >= W) break;
-      const float2* r = red + (slot * XB + i) * CH8;
-      float mean = 0.f;
-      for (int k = 0; k < CH8; ++k) mean += r[k].x;
-      mean /= CH8;
-      float m2 = 0.f;
-      for (int k = 0; k < CH8; ++k) { const float d = r[k].x - mean; m2 += r[k].y + 8.f * d * d; }
-      const float rstd = rsqrtf(m2 / C + eps);
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (acc[i][e] - mean) * rstd * gw[e] + gb[e];
-      st8<T>(yo + (long)(x0 + i) * C, o);
-    }
-  } else {
-    if (!live) return;
-    float sc[8], sh[8];
-    ld8<float>(scale + c0, sc);
-    ld8<float>(shift + c0, sh);
-    T* yo = y + (((long)n * H + yy) * W) * C + c0;
-#pragma unroll
-    for (int i = 0; i < XB; ++i) {
-      if (x0 + i >= W) break;
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = act_apply(acc[i][e] * sc[e] + sh[e], act);
-      st8<T>(yo + (long)(x0 + i) * C, o);
-    }
   }
 }
 
@@ -371,39 +255,6 @@ extern "C" int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float*
   else if (out_dtype == MTBT_BF16)
     hipLaunchKernelGGL((stem_kernel<bf16_t, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, N, H, W, Cout, G);
   else return MTBT_EINVAL;
-  MTBT_LAUNCH_CHECK();
-  return MTBT_OK;
-}
-
-extern "C" int mtbt_dwconv_nhwc(const void* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
-                                float ln_eps, const float* scale, const float* shift, int act, void* y, int N, int H,
-                                int W, int C, int ksize, int dtype, void* stream) {
-  if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
-  if (ksize != 3 && ksize != 7) return MTBT_EINVAL;
-  const bool ln = ln_w != nullptr;
-  if (ln && (!ln_b || !bias)) return MTBT_EINVAL;
-  if (!ln && (!scale || !shift)) return MTBT_EINVAL;
-  if (!aligned16(x) || !aligned16(y) || !aligned16(w)) return MTBT_EALIGN;
-  const int CH8 = C / 8;
-  int slots = 256 / CH8;
-  if (slots < 1) slots = 1;
-  const int threads = slots * CH8;
-  const long items = (long)N * H * ((W + 3) / 4);
-  const long blocks = (items + slots - 1) / slots;
-  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
-  const size_t lds = ln ? (size_t)slots * 4 * CH8 * sizeof(float2) : 0;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define DW_LAUNCH(T, KS, LN)                                                                                         \
-  hipLaunchKernelGGL((dwconv_kernel<T, KS, LN>), dim3((unsigned)blocks), dim3(threads), lds, s, (const T*)x, w, bias, ln_w, \
-                     ln_b, ln_eps, scale, shift, act, (T*)y, N, H, W, C, slots)
-  if (dtype == MTBT_F32) {
-    if (ksize == 7) { if (ln) DW_LAUNCH(float, 7, true); else DW_LAUNCH(float, 7, false); }
-    else { if (ln) DW_LAUNCH(float, 3, true); else DW_LAUNCH(float, 3, false); }
-  } else if (dtype == MTBT_BF16) {
-    if (ksize == 7) { if (ln) DW_LAUNCH(bf16_t, 7, true); else DW_LAUNCH(bf16_t, 7, false); }
-    else { if (ln) DW_LAUNCH(bf16_t, 3, true); else DW_LAUNCH(bf16_t, 3, false); }
-  } else return MTBT_EINVAL;
-#undef DW_LAUNCH
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

@@ -258,7 +258,7 @@ class _Lowering:
         """ultralytics DWConv: depthwise 3x3 + BN + SiLU."""
         self._need_eval(mod.bn, name)
         scale, shift = _bn_fold(mod.bn)
-        w = self.F(mod.conv.weight.detach().reshape(x.C, 9).t())
+        w = self.W(mod.conv.weight.detach().reshape(x.C, 9).t())
         y = self.p.new(x.N, x.H, x.W, x.C, self.code)
         self.p.dwconv(x, w, y, 3, scale=self.F(scale), shift=self.F(shift), act=L.ACT_SILU, name=name)
         return y
@@ -317,7 +317,7 @@ class _Lowering:
             for bi, blk in enumerate(st.blocks):
                 bn_ = f"{nm}.blocks.{bi}"
                 t = self.p.new(a.N, a.H, a.W, d, self.code)
-                self.p.dwconv(a, self.F(blk.conv_dw.weight.detach().reshape(d, 49).t()), t, 7, bias=self.F(blk.conv_dw.bias),
+                self.p.dwconv(a, self.W(blk.conv_dw.weight.detach().reshape(d, 49).t()), t, 7, bias=self.F(blk.conv_dw.bias),
                               lnw=self.F(blk.norm.weight), lnb=self.F(blk.norm.bias), eps=blk.norm.eps, name=bn_ + ".conv_dw+norm")
                 h = self.p.new(a.N, a.H, a.W, 4 * d, self.code)
                 self.p.conv(t, self.W(blk.mlp.fc1.weight), h, shift=self.F(blk.mlp.fc1.bias), act=L.ACT_GELU, name=bn_ + ".mlp.fc1")

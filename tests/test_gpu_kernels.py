@@ -152,7 +152,7 @@ def test_stem(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 96, 9, 11), (1, 192, 8, 8), (1, 768, 5, 6), (1, 384, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 96, 9, 11), (1, 192, 8, 8), (1, 768, 5, 6), (1, 384, 4, 4), (1, 96, 20, 37), (2, 384, 17, 16)])
 def test_dwconv7_layernorm(dtype, shape):
     N, Cc, H, W = shape
     g = torch.Generator().manual_seed(6)
@@ -160,13 +160,15 @@ def test_dwconv7_layernorm(dtype, shape):
     if dtype == torch.bfloat16:
         x = x.bfloat16().float()
     w = torch.randn(Cc, 1, 7, 7, generator=g) / 7
+    if dtype == torch.bfloat16:
+        w = w.bfloat16().float()
     b = torch.randn(Cc, generator=g) * 0.1
     lw, lb = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
     y = F.conv2d(x, w, b, 1, 3, groups=Cc)
     ref = F.layer_norm(y.permute(0, 2, 3, 1), (Cc,), lw, lb, 1e-6).permute(0, 3, 1, 2)
     p = Plan(torch.device(DEV))
     ya = Act.of(torch.zeros(N, H, W, Cc, dtype=dtype, device=DEV))
-    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 49).t().contiguous().to(DEV), ya, 7, bias=b.to(DEV), lnw=lw.to(DEV),
+    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 49).t().contiguous().to(DEV, dtype), ya, 7, bias=b.to(DEV), lnw=lw.to(DEV),
              lnb=lb.to(DEV), eps=1e-6)
     run(p)
     tol = TOL32 if dtype == torch.float32 else 3e-2
@@ -181,11 +183,13 @@ def test_dwconv3_affine_silu(dtype):
     if dtype == torch.bfloat16:
         x = x.bfloat16().float()
     w = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    if dtype == torch.bfloat16:
+        w = w.bfloat16().float()
     sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
     ref = F.silu(F.conv2d(x, w, None, 1, 1, groups=Cc) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     p = Plan(torch.device(DEV))
     ya = Act.of(torch.zeros(N, H, W, Cc, dtype=dtype, device=DEV))
-    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 9).t().contiguous().to(DEV), ya, 3, scale=sc.to(DEV), shift=sh.to(DEV), act=1)
+    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 9).t().contiguous().to(DEV, dtype), ya, 3, scale=sc.to(DEV), shift=sh.to(DEV), act=1)
     run(p)
     tol = TOL32 if dtype == torch.float32 else 3e-2
     assert (back(ya.buf) - ref).abs().max().item() < tol
