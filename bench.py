@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
+    ap.add_argument("--ab", default="", help="dev: comma list of MTBT_CONV_POLICY values to A/B inside this process")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +116,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if rank == 0 and args.ab:
+        import re, collections
+        def cat(n):
+            for k, pat in [("dw7+LN", "conv_dw"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2"), ("downsample", "downsample"), ("stem", "stem"),
+                           ("fuse", "fuse"), ("proto", "proto"), ("c2f 3x3", r"\.m\.\d\.cv"), ("head dw3", r"cv3\.\d\.\d\.0"),
+                           ("head 3x3", r"(detect|segment)\.cv[234]\.\d\.[01]$"), ("bifpn pw", r"_conv$"), ("cls", "cls_pool")]:
+                if re.search(pat, n):
+                    return k
+            return "1x1 other"
+        for rnd in range(2):
+            for pol in args.ab.split(","):
+                os.environ["MTBT_CONV_POLICY"] = pol
+                model.__dict__.pop("_plans", None)
+                c = model.compile(x)
+                c.plan.run(); c.plan.run()
+                ms = c.plan.run_timed()
+                agg = collections.OrderedDict()
+                for l, t in zip(c.plan.launches, ms):
+                    agg[cat(l.name)] = agg.get(cat(l.name), 0.0) + t
+                print(f"policy {pol} round {rnd}: total {sum(ms):.3f} ms | " + " ".join(f"{k}={v*1e3:.0f}" for k, v in agg.items()), file=sys.stderr)
+        os.environ.pop("MTBT_CONV_POLICY", None)
+        model.__dict__.pop("_plans", None)
     if rank == 0:
         # ---- roofline of the dominant kernel family: instrumented replay of the same plan ----
         c = model.compile(x)

@@ -1,24 +1,48 @@
 // C entry point of the implicit-GEMM convolution: argument validation, tile / pipeline-depth heuristics and
 // dispatch to the per-dtype translation units (conv_igemm_bf16.hip, conv_igemm_f32.hip; kernel in conv_igemm.inc).
+#include <cstdlib>
+
 #include "common.h"
 #include "conv_params.h"
 
 int mtbt_conv_dispatch_bf16(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
 int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
 
-// Tile heuristic: channel tile with the least padding waste (ties -> larger), pixel tile 128 unless
-// that leaves the 256 CUs under-filled.
-static void pick_tile(int K, long M, int* TC, int* TP) {
-  const int cands[4] = {128, 96, 64, 32};
-  long best_waste = -1;
-  int best = 128;
-  for (int c : cands) {
-    const long padded = (long)((K + c - 1) / c) * c;
-    if (best_waste < 0 || padded < best_waste) { best_waste = padded; best = c; }
+// Tile heuristics, from the sweep in tools/conv_tune.py on the shapes of the 640x640 batch-16 forward
+// (numbers in DESIGN.md):
+//   * channel tile = the divisor of K among 128 / 96 (else the smallest tile that covers K);
+//   * 1x1 convolutions (streaming GEMMs, HBM-bound): a SMALL 128x64 / 96x128 / 64x128 tile with 64-byte K-steps
+//     -> 32 KiB of LDS, three or more workgroups per CU hide the load / epilogue latency of the short K loop;
+//   * k x k convolutions (MFMA-bound): 128-pixel tiles with 128-byte K-steps while that still gives >= 2
+//     workgroups per CU, else 64x64 (small pyramid levels, 64-channel head convs).
+static void pick_tile(int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow) {
+  // development knob (A/B inside one process): MTBT_CONV_POLICY bit0 = small 1x1 tiles, bit1 = 64x64 for small k x k
+  const char* pol_s = getenv("MTBT_CONV_POLICY");
+  const int pol = pol_s ? atoi(pol_s) : 3;
+  int tc;
+  if (K % 128 == 0) tc = 128;
+  else if (K % 96 == 0) tc = 96;
+  else if (K > 96) tc = 128;
+  else if (K > 64) tc = 96;
+  else if (K > 32) tc = 64;
+  else tc = 32;
+  const long ct = (K + tc - 1) / tc;
+  if (taps == 1 && (pol & 1)) {
+    *TC = tc;
+    *TP = (tc == 128) ? 64 : 128;
+    *narrow = (C * es <= 1536) ? 1 : 0;
+    return;
   }
-  *TC = best;
-  const long ct = (K + best - 1) / best;
-  *TP = (((M + 127) / 128) * ct >= 512) ? 128 : 64;
+  *narrow = 0;
+  if (!(pol & 2) || taps == 1) {  // round-1 baseline: largest fitting channel tile, 128 pixels unless the grid is tiny
+    *TC = tc;
+    *TP = (((M + 127) / 128) * ct >= 512) ? 128 : 64;
+    return;
+  }
+  if (K <= 64) { *TC = K > 32 ? 64 : 32; *TP = 64; return; }
+  if (((M + 127) / 128) * ct >= 512) { *TC = tc; *TP = 128; return; }
+  *TC = (tc == 96) ? 96 : 64;
+  *TP = 64;
 }
 
 // LDS stages: as deep as fits 64 KiB (two workgroups per CU stay resident), at least 2, no deeper than the K loop.
@@ -27,7 +51,7 @@ static int pick_nbuf(int TC, int TP, int BKB, int nsteps) {
   const int tcs = ((TC * cpr + 255) / 256) * 256 / cpr;
   const int bufsz = (tcs + TP) * BKB;
   int n = 64 * 1024 / bufsz;
-  if (n > 4) n = 4;
+  if (n > 2) n = 2;  // deeper pipelines never paid in the sweep: residency (workgroups per CU) beats prefetch depth
   if (n > nsteps) n = nsteps;
   if (n < 2) n = 2;
   return n;
@@ -77,9 +101,10 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   p.vec_ok = vec ? 1 : 0;
 
   int TC, TP, nbuf = 0;
-  if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0xfff; TP = a->tile_hint & 0xffff; }
-  if (!a->tile_hint || !TC || !TP) pick_tile(a->K, p.M, &TC, &TP);
-  const int wide = (a->C % (128 / es) == 0) ? 1 : 0;
+  if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x7ff; TP = a->tile_hint & 0xffff; }
+  int narrow = (a->tile_hint >> 27) & 1;  // hint bit 27: force 64-byte K-steps
+  if (!a->tile_hint || !TC || !TP) pick_tile(a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow);
+  const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == MTBT_F32) return mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s);

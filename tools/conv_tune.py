@@ -60,19 +60,20 @@ def bench(shape, hint, dtype=torch.bfloat16, iters=20):
 
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
-    hints = [(0, 0, 0)] + [(nb, tc, tp) for tc, tp in [(128, 128), (128, 64), (64, 128), (96, 128), (64, 64)] for nb in (2, 3, 4)]
+    hints = [(0, 0, 0, 0)] + [(nb, tc, tp, nar) for tc, tp in [(128, 128), (128, 64), (64, 128), (96, 128), (64, 64)]
+                              for nar in (0, 1) for nb in (2, 3, 4) if not (nar == 0 and nb == 4)]
     for name, shape in SHAPES.items():
         if flt and flt not in name:
             continue
         print(f"== {name}")
-        for nb, tc, tp in hints:
+        for nb, tc, tp, nar in hints:
             K = shape[4]
             if tc and ((tc == 96 and K % 96) or (tc == 128 and K < 96) or (tc == 64 and K % 64 and K > 64)):
                 continue
-            tf, gb, t = bench(shape, (nb << 28) | (tc << 16) | tp)
+            tf, gb, t = bench(shape, (nb << 28) | (nar << 27) | (tc << 16) | tp)
             if tf is None:
                 continue
-            print(f"   nbuf={nb} tile={tc:3d}x{tp:3d}: {tf:7.1f} TF/s {gb:7.0f} GB/s  {t}")
+            print(f"   nbuf={nb} bk={'64B ' if nar else '128B'} tile={tc:3d}x{tp:3d}: {tf:7.1f} TF/s {gb:7.0f} GB/s  {t}")
 
 
 if __name__ == "__main__":
