@@ -1,0 +1,165 @@
+// Prototype x coefficient mask assembly, x4 upsampling fast path (the model's case: protos at S/4).
+//
+//   low[k][y][x] = sum_c coeff[k][c] * protos[y][x][c] (+ bias)      -- MFMA, exact fp32 (v_mfma_f32_16x16x4_f32)
+//   up = bilinear x4 (align_corners=False);  mask = sigmoid(up) > 0.5
+//
+// The general kernel (postprocess.hip) re-reads the 18x18x32 prototype halo patch for every box: at 100
+// boxes x 100 tiles x 16 images that is ~6.5 GB of L2 traffic, and its per-pixel index arithmetic + exp
+// made it VALU-bound at 0.6 TB/s of output.  Here a workgroup owns one 64x64 output tile of one image:
+//   1. the prototype halo patch (18x18 low-res pixels x 32 channels, coordinates CLAMPED to the image so the
+//      edge rule of torch's bilinear falls out of the uniform interior formula) is staged in LDS once;
+//   2. boxes are processed 16 at a time: coefficients [16 x 32] x patch [32 x 324] on the fp32 MFMA
+//      (rows = boxes, columns = low-res pixels, 8 K-steps of 4 channels) -> low-res masks in LDS;
+//   3. each thread upsamples 16 consecutive output pixels of one row per box with compile-time x4 weights
+//      (frac = .625 .875 .125 .375 ...), horizontal-then-vertical like torch, and stores 16 mask bytes
+//      (one 16-B store) and/or 16 logits.
+// sigmoid(v) > 0.5 in fp32 is exactly v > 2^-24 (1 + exp(-v) rounds to 2 below that), so no exp is evaluated.
+#include "common.h"
+
+namespace {
+
+struct MaskX4P {
+  const float* protos;
+  const float* coeff;
+  long cbs, cks, ccs;
+  const int* gather;
+  const int* counts;
+  float bias;
+  int N, K, hp, wp, Hout, Wout;
+  float* logits;
+  unsigned char* masks;
+  int tiles_x, tiles_y;
+};
+
+constexpr int NM = 32;          // prototype channels
+constexpr int PW = 18;          // patch edge (16 + halo)
+constexpr int NPX = PW * PW;    // 324 low-res pixels
+constexpr int NPXP = 336;       // padded to 21 MFMA column groups
+constexpr int PPITCH = NM + 1;  // patch row pitch (floats): conflict-free column reads
+constexpr int LPITCH = NPXP + 4;
+
+__global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* patch = reinterpret_cast<float*>(smem);       // [NPXP][PPITCH]
+  float* coef = patch + NPXP * PPITCH;                 // [16][PPITCH]
+  float* low = coef + 16 * PPITCH;                     // [16][LPITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y;
+  const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+  const int lx_base = tx * 16 - 1, ly_base = ty * 16 - 1;
+  const int cnt = p.counts ? min(p.counts[n], p.K) : p.K;
+
+  // 1. stage the clamped halo patch
+  const float* pr = p.protos + (long)n * p.hp * p.wp * NM;
+  for (int i = tid; i < NPXP * (NM / 4); i += 256) {
+    const int px = i >> 3, c4 = i & 7;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (px < NPX) {
+      const int py = px / PW, pxx = px - py * PW;
+      const int ly = min(max(ly_base + py, 0), p.hp - 1), lx = min(max(lx_base + pxx, 0), p.wp - 1);
+      v = *reinterpret_cast<const float4*>(pr + ((long)ly * p.wp + lx) * NM + c4 * 4);
+    }
+    float* d = patch + px * PPITCH + c4 * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+
+  const int row = tid >> 2, seg = tid & 3;  // upsample role: output row of the tile, 16-pixel segment
+  const int oy = ty * 64 + row, ox0 = tx * 64 + seg * 16;
+  // vertical taps of this thread's row (x4): low row index inside the patch and weight
+  const int iy = (row + 2) >> 2;
+  const float wy1 = ((row + 2) & 3) * 0.25f + 0.125f, wy0 = 1.0f - wy1;
+
+  for (int g0 = 0; g0 < cnt; g0 += 16) {
+    // 2a. coefficients of boxes g0..g0+15 (zeros past cnt)
+    for (int i = tid; i < 16 * NM; i += 256) {
+      const int b = i >> 5, c = i & 31;
+      float v = 0.f;
+      if (g0 + b < cnt) {
+        const long kk = p.gather ? p.gather[(long)n * p.K + g0 + b] : (g0 + b);
+        v = p.coeff[(long)n * p.cbs + kk * p.cks + c * p.ccs];
+      }
+      coef[b * PPITCH + c] = v;
+    }
+    __syncthreads();
+    // 2b. low[16][NPXP] = coef[16][32] x patch^T on the fp32 MFMA; wave w takes column groups w, w+4, ...
+    {
+      float a[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) a[ks] = coef[(lane & 15) * PPITCH + ks * 4 + (lane >> 4)];
+      for (int pg = wave; pg < NPXP / 16; pg += 4) {
+        f32x4 acc = f32x4{p.bias, p.bias, p.bias, p.bias};
+        const float* bp = patch + (pg * 16 + (lane & 15)) * PPITCH + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bp[ks * 4], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) low[(4 * (lane >> 4) + r) * LPITCH + pg * 16 + (lane & 15)] = acc[r];
+      }
+    }
+    __syncthreads();
+    // 2c. x4 bilinear + threshold, 16 pixels per thread per box
+    if (oy < p.Hout) {
+      const int nb = min(16, cnt - g0);
+      for (int b = 0; b < nb; ++b) {
+        const float* r0 = low + b * LPITCH + iy * PW + seg * 4;
+        const float* r1 = r0 + PW;
+        float t0[6], t1[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { t0[c] = r0[c]; t1[c] = r1[c]; }
+        float o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ix = (e + 2) >> 2;                                   // compile-time
+          const float wx1 = ((e + 2) & 3) * 0.25f + 0.125f, wx0 = 1.0f - wx1;
+          o[e] = wy0 * (wx0 * t0[ix] + wx1 * t0[ix + 1]) + wy1 * (wx0 * t1[ix] + wx1 * t1[ix + 1]);
+        }
+        const long obase = (((long)n * p.K + g0 + b) * p.Hout + oy) * p.Wout + ox0;
+        if (p.logits) {
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(p.logits + obase + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
+        }
+        if (p.masks) {
+          unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 16; ++e) w[e >> 2] |= (o[e] > 5.9604645e-8f ? 1u : 0u) << ((e & 3) * 8);
+          *reinterpret_cast<uint4*>(p.masks + obase) = uint4{w[0], w[1], w[2], w[3]};
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // 3. padded slots k >= cnt: zeros
+  if (oy < p.Hout) {
+    for (int k = cnt; k < p.K; ++k) {
+      const long obase = (((long)n * p.K + k) * p.Hout + oy) * p.Wout + ox0;
+      if (p.logits) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(p.logits + obase + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (p.masks) *reinterpret_cast<uint4*>(p.masks + obase) = uint4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
+}  // namespace
+
+// Returns MTBT_OK if the fast path applied, 1 if the shape is not the x4 case (caller falls back).
+int mtbt_mask_x4_try(const mtbt_mask_args* a, hipStream_t stream) {
+  if (a->nm != NM || a->Hout != 4 * a->hp || a->Wout != 4 * a->wp || a->Wout % 64 || a->Hout % 4) return 1;
+  MaskX4P p;
+  p.protos = a->protos; p.coeff = a->coeff; p.cbs = a->coeff_batch_stride; p.cks = a->coeff_k_stride; p.ccs = a->coeff_c_stride;
+  p.gather = a->gather_idx; p.counts = a->counts; p.bias = a->bias;
+  p.N = a->N; p.K = a->K; p.hp = a->hp; p.wp = a->wp; p.Hout = a->Hout; p.Wout = a->Wout;
+  p.logits = a->logits; p.masks = a->masks;
+  p.tiles_x = a->Wout / 64;
+  p.tiles_y = (a->Hout + 63) / 64;
+  const size_t lds = (size_t)(NPXP * PPITCH + 16 * PPITCH + 16 * LPITCH) * sizeof(float);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    attr_set = true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_x4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return MTBT_ELAUNCH;
+  }
+  hipLaunchKernelGGL(mask_x4_kernel, dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}

@@ -407,6 +407,8 @@ extern "C" int mtbt_nms_batched(const float* boxes, const float* best_score, con
   return MTBT_OK;
 }
 
+int mtbt_mask_x4_try(const mtbt_mask_args* a, hipStream_t stream);  // mask_mfma.hip: MFMA fast path for x4 upsampling
+
 extern "C" int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream) {
   if (!a || !a->protos || !a->coeff || (!a->logits && !a->masks)) return MTBT_EINVAL;
   if (a->N <= 0 || a->K <= 0 || a->nm <= 0 || a->nm > 64 || a->nm % 4 || a->hp <= 0 || a->wp <= 0) return MTBT_EINVAL;
@@ -415,6 +417,10 @@ extern "C" int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream) {
   if (!aligned16(a->protos)) return MTBT_EALIGN;
   if (a->logits && !aligned16(a->logits)) return MTBT_EALIGN;
   if (a->masks && !aligned16(a->masks)) return MTBT_EALIGN;
+  {
+    const int rc = mtbt_mask_x4_try(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc != 1) return rc;
+  }
   MaskP p;
   p.protos = a->protos; p.coeff = a->coeff; p.cbs = a->coeff_batch_stride; p.cks = a->coeff_k_stride; p.ccs = a->coeff_c_stride;
   p.gather = a->gather_idx; p.counts = a->counts; p.bias = a->bias;

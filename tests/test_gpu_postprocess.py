@@ -117,26 +117,29 @@ def test_nms_large_anchor_count_global_sort_path():
     assert n == len(k) and torch.equal(out["keep_idx"][0, :n].cpu(), k)
 
 
-def test_mask_assembly_and_projector():
+@pytest.mark.parametrize("hp,wp", [(40, 40), (64, 64), (40, 64), (16, 16)])  # general path / MFMA x4 fast path (W % 64 == 0)
+def test_mask_assembly_and_projector(hp, wp):
     g = torch.Generator().manual_seed(11)
-    B, nm, hp, A, K, S = 2, 32, 40, 300, 7, 160
-    protos = torch.randn(B, nm, hp, hp, generator=g)
+    B, nm, A, K = 2, 32, 300, 21
+    SH, SW = 4 * hp, 4 * wp
+    protos = torch.randn(B, nm, hp, wp, generator=g)
     mc = torch.randn(B, A, nm, generator=g).permute(0, 2, 1)  # logical [B,nm,A], strided like the model's
     keep_anchor = torch.randint(0, A, (B, K), generator=g, dtype=torch.int32)
     counts = torch.tensor([K, 3], dtype=torch.int32)
     masks, logits = pp.assemble_masks(protos.to(DEV).contiguous(memory_format=torch.channels_last), mc.to(DEV), keep_anchor.to(DEV),
-                                      counts.to(DEV), (S, S), want_logits=True)
+                                      counts.to(DEV), (SH, SW), want_logits=True)
     torch.cuda.synchronize()
     for b in range(B):
         n = int(counts[b])
         coeffs = mc[b, :, keep_anchor[b, :n].long()].t()
-        ref_logits, ref_masks = opp.assemble_masks(coeffs, protos[b], (S, S))
+        ref_logits, ref_masks = opp.assemble_masks(coeffs, protos[b], (SH, SW))
         assert (logits[b, :n].cpu() - ref_logits).abs().max().item() < 1e-3
         diff = masks[b, :n].cpu() != ref_masks
         assert torch.all(ref_logits[diff].abs() < 1e-4)  # only sign-ambiguous pixels may differ
         assert not masks[b, n:].any()
-    w, bias = torch.randn(nm, generator=g) / 6, torch.tensor([0.3])
-    out = pp.proto_projector_logits(protos.to(DEV), w.to(DEV), bias.to(DEV), S)
-    torch.cuda.synchronize()
-    ref = opp.proto_projector_logits(protos, w, bias, S)
-    assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 1e-3
+    if hp == wp:
+        w, bias = torch.randn(nm, generator=g) / 6, torch.tensor([0.3])
+        out = pp.proto_projector_logits(protos.to(DEV), w.to(DEV), bias.to(DEV), SH)
+        torch.cuda.synchronize()
+        ref = opp.proto_projector_logits(protos, w, bias, SH)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 1e-3
