@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the ~220 launches of a step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
     ap.add_argument("--ab", default="", help="dev: comma list of MTBT_CONV_POLICY values to A/B inside this process")
     args = ap.parse_args()
@@ -83,7 +84,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, init_synthetic_, postprocess as pp
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, GraphedInference, init_synthetic_, postprocess as pp
 
     torch.manual_seed(0)
     model = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
@@ -91,30 +92,30 @@ def main():
     B = args.batch
     x = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(rank)).to(dev)  # resident in HBM
 
-    def step():
+    def eager_step():
         with torch.no_grad():
             out = model(x, "infer")
             feats, mc, protos = out["segment_protos"]
             return pp.detect_and_segment(out["detect_features"], mc, protos, IMG)
 
-    def fence():
+    if args.no_graph:
+        step = eager_step
+    else:
+        # the same step (drop-in forward + post-process), captured once into a HIP graph and replayed
+        graphed = GraphedInference(model, x, IMG)
+        ref = eager_step()
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        got = graphed.replay()
         torch.cuda.synchronize(dev)
+        assert torch.equal(got["keep_idx"], ref["keep_idx"]) and torch.equal(got["masks"], ref["masks"]), "graph replay != eager step"
+        step = graphed.replay
 
+    from multitask_bonetumor_yolo_amd.dist_utils import timed_steps
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # barrier + synchronize on both sides of exactly K steps, MAX over ranks (tested on CPU with gloo, world size 2)
+    elapsed = timed_steps(step, args.steps, lambda: torch.cuda.synchronize(dev))
+    res = step()
 
     if rank == 0 and args.ab:
         import re, collections

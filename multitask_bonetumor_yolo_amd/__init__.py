@@ -7,4 +7,5 @@ The HIP library (csrc/libmtbt_hip.so, C ABI in include/mtbt_hip.h) is built by
 `python -m multitask_bonetumor_yolo_amd.build`; nothing here falls back to the CPU.
 """
 from . import postprocess  # noqa: F401
+from .graphed import GraphedInference  # noqa: F401
 from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv2, init_synthetic_  # noqa: F401
