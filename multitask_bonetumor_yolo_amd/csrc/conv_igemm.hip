@@ -7,6 +7,8 @@
 
 int mtbt_conv_dispatch_bf16(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
 int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
+int mtbt_conv3x3_direct_bf16(const ConvP& p, int TC, hipStream_t s);
+int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s);
 
 // Tile heuristics, from the sweep in tools/conv_tune.py on the shapes of the 640x640 batch-16 forward
 // (numbers in DESIGN.md):
@@ -18,7 +20,7 @@ int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, h
 static void pick_tile(int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow) {
   // development knob (A/B inside one process): MTBT_CONV_POLICY bit0 = small 1x1 tiles, bit1 = 64x64 for small k x k
   const char* pol_s = getenv("MTBT_CONV_POLICY");
-  const int pol = pol_s ? atoi(pol_s) : 3;
+  const int pol = pol_s ? atoi(pol_s) : 7;
   int tc;
   if (K % 128 == 0) tc = 128;
   else if (K % 96 == 0) tc = 96;
@@ -86,6 +88,7 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
                (!a->res || a->res_batch_stride == (int64_t)a->Ho * a->Wo * a->res_pixel_stride);
   p.ctiles = 0;
   p.ptiles_per_xcd = 0;
+  { const char* d = getenv("MTBT_CONV_DEBUG"); p.debug = d ? atoi(d) : 0; }
   // LDS-DMA addressing: 32-bit byte offsets below 2 GiB relative to (first image of a tile, weight tile row 0)
   if ((double)a->R * a->S > 31) return MTBT_EINVAL;
   if (((long)(128 / (a->Ho * a->Wo) + 2) * a->x_batch_stride + 2L * ((long)a->pad * a->W + a->pad) * a->x_pixel_stride) * es >= 0x7fff0000L) return MTBT_EINVAL;
@@ -100,13 +103,25 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   if (a->res) vec = vec && (a->res_pixel_stride % epc == 0) && (a->res_batch_stride % epc == 0) && aligned16(a->res);
   p.vec_ok = vec ? 1 : 0;
 
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // 3x3 / stride 1 / pad 1 on 16-aligned maps: direct convolution with an LDS-resident halo tile (conv3x3_direct.inc).
+  // tile_hint bit 26 (or MTBT_CONV_POLICY bit 2 cleared) keeps such a conv on the implicit-GEMM kernel (tests, A/B).
+  {
+    const char* pol_s = getenv("MTBT_CONV_POLICY");
+    const int pol = pol_s ? atoi(pol_s) : 7;
+    if ((pol & 4) && !((a->tile_hint >> 26) & 1) && a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->H % 16 == 0 &&
+        a->W % 16 == 0 && a->out_mode == MTBT_OUT_NHWC && a->C % (128 / es) == 0 && a->K > 32 &&
+        (long)a->H * a->W * a->x_pixel_stride * es < 0x7fff0000L && (long)128 * 9 * a->C * es < 0x7fff0000L) {
+      const int tc = a->K >= 96 ? 128 : 64;
+      return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s);
+    }
+  }
   int TC, TP, nbuf = 0;
-  if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x7ff; TP = a->tile_hint & 0xffff; }
+  if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x3ff; TP = a->tile_hint & 0xffff; }
   int narrow = (a->tile_hint >> 27) & 1;  // hint bit 27: force 64-byte K-steps
   if (!a->tile_hint || !TC || !TP) pick_tile(a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow);
   const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == MTBT_F32) return mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s);
   return mtbt_conv_dispatch_bf16(p, TC, TP, wide, nbuf, s);
 }

@@ -1,7 +1,14 @@
 // fp32 (exact-fp32 MFMA, parity mode) instantiations of the implicit-GEMM conv (see conv_igemm.inc).
 #include "conv_igemm.inc"
+#include "conv3x3_direct.inc"
 
 int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s) {
   if (wide) return nbuf >= 3 ? dispatch_tile<float, 128, 3>(p, TC, TP, s) : dispatch_tile<float, 128, 2>(p, TC, TP, s);
   return nbuf >= 3 ? dispatch_tile<float, 64, 3>(p, TC, TP, s) : dispatch_tile<float, 64, 2>(p, TC, TP, s);
+}
+
+int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s) {
+  if (TC == 128) return launch_direct3x3<float, 128>(p, s);
+  if (TC == 64) return launch_direct3x3<float, 64>(p, s);
+  return MTBT_EINVAL;
 }

@@ -16,4 +16,5 @@ struct ConvP {
   int M;       // N*Ho*Wo (< 2^31)
   int ctiles;  // ceil(K / TC)
   int ptiles_per_xcd;  // ceil(ceil(M / TP) / 8)
+  int debug;  // development ablation bits (MTBT_CONV_DEBUG): 1 = no DMA in the K loop, 2 = no fragment reads / MFMAs
 };

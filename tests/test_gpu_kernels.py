@@ -52,6 +52,10 @@ ACTS = {0: lambda v: v, 1: F.silu, 2: F.elu, 3: F.gelu}
     (1, 16, 16, 64, 48, 3, 1, 1, 1, False, (32 << 16) | 128),
     (1, 16, 16, 64, 48, 3, 1, 1, 1, False, (32 << 16) | 64),
     (1, 1, 1, 32, 16, 1, 1, 0, 0, False, 0),         # single pixel
+    (2, 32, 48, 128, 256, 3, 1, 1, 1, True, 0),      # direct 3x3 (LDS halo tile): 2 channel tiles, residual, 2 images
+    (1, 16, 32, 64, 64, 3, 1, 1, 2, False, 0),       # direct 3x3, TC=64, single channel chunk
+    (1, 48, 16, 192, 96, 3, 1, 1, 1, False, 0),      # direct 3x3, K=96 (ragged channel tile), 3 chunks
+    (2, 32, 48, 128, 256, 3, 1, 1, 1, True, 1 << 26),  # same shape forced onto the implicit-GEMM kernel
 ])
 def test_conv_igemm(dtype, cfg):
     N, H, W, Cin, K, k, st, pad, act, use_res, hint = cfg
