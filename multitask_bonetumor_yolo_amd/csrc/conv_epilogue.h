@@ -1,0 +1,90 @@
+// Shared epilogue of the MFMA conv kernels.
+//
+// Accumulator layout (16x16 MFMA, rows = channels): lane (lr = lane&15, lq = lane>>4) holds, per fragment
+// (i, j), channels 16 i + 4 lq .. +3 of pixel 16 j + lr.  Per 16-pixel slab j:
+//   (1) affine (+ activation) in fp32 and a float4 store into the wave's [16 px][WCH ch] fp32 LDS slab
+//       (row pitch +16 B: conflict-free b128 writes); scale/shift come from a per-workgroup LDS copy;
+//   (2) lanes re-read the slab as rows: 8 consecutive channels of one pixel per lane (two ds_read_b128),
+//       add the residual (one 16-byte load) and issue ONE 16-byte (bf16) / two 16-byte (f32) coalesced stores.
+// The caller guarantees the main loop is over (barrier) before the slabs are written.
+#pragma once
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+// Stage this workgroup's TC (scale, shift) pairs in LDS: aff[0..TC) = scale, aff[TC..2TC) = shift.
+template <int TC>
+__device__ __forceinline__ void stage_affine(const ConvP& p, float* aff, int cbase, int tid) {
+  for (int c = tid; c < TC; c += 256) {
+    const bool ok = cbase + c < p.K;
+    aff[c] = (ok && p.scale) ? p.scale[cbase + c] : 1.f;
+    aff[TC + c] = (ok && p.shift) ? p.shift[cbase + c] : 0.f;
+  }
+}
+
+// AddrFn: bool operator()(int j, int row, long& pixel_offset_y, long& pixel_offset_res) -- offsets in elements of the
+// slab pixel (without the channel), false if the pixel is outside the output.
+template <typename T, int TC, int FC, int FP, typename AddrFn>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
+                                              int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr) {
+  constexpr int WCH = FC * 16;
+  constexpr int PITCH = WCH * 4 + 16;
+  constexpr int C8 = WCH / 8;
+  constexpr int ITER = (16 * C8 + 63) / 64;
+  const int lr = lane & 15, lq = lane >> 4;
+  const bool has_scale = p.scale != nullptr;
+#pragma clang loop unroll(full)  // must unroll: a runtime j would put the whole accumulator array in scratch
+  for (int j = 0; j < FP; ++j) {
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+      const int cl = chl0 + i * 16 + lq * 4;
+      const float4 sh = *reinterpret_cast<const float4*>(aff + TC + cl);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (has_scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(aff + cl);
+        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+      }
+      v.x = act_apply(v.x + sh.x, p.act); v.y = act_apply(v.y + sh.y, p.act);
+      v.z = act_apply(v.z + sh.z, p.act); v.w = act_apply(v.w + sh.w, p.act);
+      *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
+    }
+    // wave-local hand-off through LDS (other lanes' data): a compiler barrier is REQUIRED -- the float4 row reads
+    // below are a different type from the stores above and would otherwise be hoisted over them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * 64 + lane;
+      if ((16 * C8) % 64 != 0 && idx >= 16 * C8) break;
+      const int row = idx / C8, c8 = idx - row * C8;
+      const int ch = cbase + chl0 + c8 * 8;
+      long yoff, roff;
+      if (ch >= p.K || !addr(j, row, ch, yoff, roff)) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32);
+      const float4 hi = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32 + 16);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (p.vec_ok && ch + 8 <= p.K) {
+        if (p.res) {
+          float r[8];
+          ld8<T>(reinterpret_cast<const T*>(p.res) + roff, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y) + yoff, v);
+        else st8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + yoff, v);
+      } else {
+        // unaligned / ragged channel tail (e.g. the nc-channel class conv, the 66-wide detect map)
+        const int lim = (p.out_mode == MTBT_OUT_CONVT2X2) ? (ch / (p.K >> 2) + 1) * (p.K >> 2) : p.K;
+        for (int e = 0; e < 8 && ch + e < lim; ++e) {
+          float u = v[e];
+          if (p.res) u += ld_elem<T>(reinterpret_cast<const T*>(p.res) + roff + e);
+          if (p.out_f32) reinterpret_cast<float*>(p.y)[yoff + e] = u;
+          else reinterpret_cast<bf16_t*>(p.y)[yoff + e] = f2bf(u);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
+  }
+}
+
+}  // namespace

@@ -244,7 +244,8 @@ class _Lowering:
         scale, shift = _bn_fold(bn, conv.bias)
         if y is None:
             y = self.p.new(x.N, x.H, x.W, conv.out_channels, self.code)
-        self.p.conv(x, self.W(_krsc(conv.weight)), y, R=k, S=k, stride=1, pad=k // 2, scale=self.F(scale),
+        # the per-channel BN scale is folded into the weight rows (fp32, before the cast): the epilogue only adds the shift
+        self.p.conv(x, self.W(_krsc(conv.weight).float() * scale[:, None]), y, R=k, S=k, stride=1, pad=k // 2,
                     shift=self.F(shift), act=L.ACT_SILU, name=name)
         return y
 
@@ -288,7 +289,7 @@ class _Lowering:
         pw = mod.pointwise.weight.detach().float().reshape(mod.pointwise.out_channels, -1) * dw
         scale, shift = _bn_fold(mod.bn)
         y = self.p.new(x.N, x.H, x.W, pw.shape[0], self.code)
-        self.p.conv(x, self.W(pw), y, scale=self.F(scale), shift=self.F(shift), act=L.ACT_ELU, name=name)
+        self.p.conv(x, self.W(pw * scale[:, None]), y, shift=self.F(shift), act=L.ACT_ELU, name=name)
         return y
 
     # -- backbone (main_model.py:33-38) --
@@ -324,8 +325,8 @@ class _Lowering:
                 self.p.release(t)
                 o = self.p.new(a.N, a.H, a.W, d, self.code)
                 g = blk.gamma.detach().float()
-                self.p.conv(h, self.W(blk.mlp.fc2.weight), o, scale=self.F(g), shift=self.F(g * blk.mlp.fc2.bias.detach().float()),
-                            res=a, name=bn_ + ".mlp.fc2")
+                self.p.conv(h, self.W(blk.mlp.fc2.weight.detach().float() * g[:, None]), o,
+                            shift=self.F(g * blk.mlp.fc2.bias.detach().float()), res=a, name=bn_ + ".mlp.fc2")
                 self.p.release(h)
                 self.p.release(a)    # block input: stem / downsample / previous block output, never a feature
                 a = o
