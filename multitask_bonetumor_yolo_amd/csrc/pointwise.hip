@@ -67,6 +67,87 @@ __global__ void stem_kernel(const float* __restrict__ x, const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem on the MFMA (bf16 output): the 4x4/4 patchify conv is a [Cout x 48] x [48 x pixels] GEMM.
+// A wave owns 16 consecutive output pixels of a row per iteration: its B fragment (8 consecutive k =
+// two kernel rows (c, ky), (c, ky+1) x 4 kx) is two float4 reads of the NCHW image, converted to bf16
+// in registers -- no LDS at all; the Cout x 64 (zero-padded) weight fragments live in registers for the
+// wave's whole grid-stride loop.  LayerNorm2d: a pixel's channels sit in the 4 lanes {n, n+16, n+32, n+48}
+// x 4 registers x Cout/16 fragments, so two xor-shuffles finish each reduction.
+// ------------------------------------------------------------------------------------------------
+template <int FCH>  // Cout / 16
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, float eps, bf16_t* __restrict__ y,
+                                                        int N, int H, int W) {
+  constexpr int Cout = FCH * 16;
+  const int lane = threadIdx.x & 63, nq = lane & 15, q = lane >> 4;
+  const int Ho = H >> 2, Wo = W >> 2;
+  const long groups = (long)N * Ho * (Wo >> 4);
+  // weight fragments: A[m = ch][k], k = 32 ks + 8 q + j, zero for k >= 48
+  bf16x8 afr[FCH][2];
+#pragma unroll
+  for (int f = 0; f < FCH; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int k0 = ks * 32 + q * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) afr[f][ks][j] = (k0 + j < 48) ? (__bf16)w[(f * 16 + nq) * 48 + k0 + j] : (__bf16)0.f;
+    }
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long g = wave_id; g < groups; g += nwaves) {
+    const int xg = (int)(g % (Wo >> 4));
+    const long ny = g / (Wo >> 4);
+    const int oy = (int)(ny % Ho), n = (int)(ny / Ho);
+    const int ox = xg * 16 + nq;
+    bf16x8 bfr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 4 + q;  // 8-wide k chunk: channel kc/2, kernel rows 2*(kc&1), +1
+      if (kc < 6) {
+        const float* src = x + (((long)n * 3 + (kc >> 1)) * H + (oy * 4 + (kc & 1) * 2)) * W + ox * 4;
+        const float4 r0 = *reinterpret_cast<const float4*>(src), r1 = *reinterpret_cast<const float4*>(src + W);
+        bfr[ks][0] = (__bf16)r0.x; bfr[ks][1] = (__bf16)r0.y; bfr[ks][2] = (__bf16)r0.z; bfr[ks][3] = (__bf16)r0.w;
+        bfr[ks][4] = (__bf16)r1.x; bfr[ks][5] = (__bf16)r1.y; bfr[ks][6] = (__bf16)r1.z; bfr[ks][7] = (__bf16)r1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bfr[ks][j] = (__bf16)0.f;
+      }
+    }
+    f32x4 acc[FCH];
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < FCH; ++f) {
+      acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[f][0], bfr[0], acc[f], 0, 0, 0);
+      acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[f][1], bfr[1], acc[f], 0, 0, 0);
+      const float4 bv = *reinterpret_cast<const float4*>(bias + f * 16 + q * 4);
+      acc[f][0] += bv.x; acc[f][1] += bv.y; acc[f][2] += bv.z; acc[f][3] += bv.w;
+      s += (acc[f][0] + acc[f][1]) + (acc[f][2] + acc[f][3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / Cout);
+    float v = 0.f;
+#pragma unroll
+    for (int f = 0; f < FCH; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = acc[f][r] - mean; v += d * d; }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const float rstd = rsqrtf(v * (1.0f / Cout) + eps);
+    bf16_t* yo = y + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
+#pragma unroll
+    for (int f = 0; f < FCH; ++f) {
+      const float4 gw = *reinterpret_cast<const float4*>(lnw + f * 16 + q * 4), gb = *reinterpret_cast<const float4*>(lnb + f * 16 + q * 4);
+      uint2 o;
+      o.x = (uint32_t)f2bf((acc[f][0] - mean) * rstd * gw.x + gb.x) | ((uint32_t)f2bf((acc[f][1] - mean) * rstd * gw.y + gb.y) << 16);
+      o.y = (uint32_t)f2bf((acc[f][2] - mean) * rstd * gw.z + gb.z) | ((uint32_t)f2bf((acc[f][3] - mean) * rstd * gw.w + gb.w) << 16);
+      *reinterpret_cast<uint2*>(yo + f * 16) = o;
+    }
+  }
+}
+
 // LayerNorm over C, one wave per pixel, values held in registers between the two passes.
 template <typename T, int MAXV>
 __global__ void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
@@ -250,6 +331,14 @@ extern "C" int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float*
   const unsigned blocks = (unsigned)((total + PIX - 1) / PIX > 4096 ? 4096 : (total + PIX - 1) / PIX);
   const size_t lds = (size_t)PIX * (48 + Cout) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (out_dtype == MTBT_BF16 && Cout == 96 && (W / 4) % 16 == 0 && bias && aligned16(w) && aligned16(bias) && aligned16(ln_w) &&
+      aligned16(ln_b) && aligned16(y)) {
+    const long groups = (long)N * (H / 4) * (W / 64);
+    const unsigned nb = (unsigned)((groups + 3) / 4 > 2048 ? 2048 : (groups + 3) / 4);
+    hipLaunchKernelGGL((stem_mfma_kernel<6>), dim3(nb), dim3(256), 0, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, N, H, W);
+    MTBT_LAUNCH_CHECK();
+    return MTBT_OK;
+  }
   if (out_dtype == MTBT_F32)
     hipLaunchKernelGGL((stem_kernel<float, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (float*)y, N, H, W, Cout, G);
   else if (out_dtype == MTBT_BF16)

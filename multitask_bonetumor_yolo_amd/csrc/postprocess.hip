@@ -38,14 +38,29 @@ __global__ void decode_kernel(const DecodeP p) {
   const int cy = cell / w, cx = cell - cy * w;
   const float* row = p.map[l] + ((long)n * hw + cell) * p.ld[l];
 
-  // distribution of this lane's side
+  // distribution of this lane's side: one pass, exponentials kept in registers (reg_max <= 16 fast path with
+  // 8-byte loads: rows are 4*reg_max+nc floats, 8-byte aligned whenever the pixel stride is even)
   const float* d = row + side * p.reg_max;
-  float m = -INFINITY;
-  for (int i = 0; i < p.reg_max; ++i) m = fmaxf(m, d[i]);
-  float s = 0.f;
-  for (int i = 0; i < p.reg_max; ++i) s += expf(d[i] - m);
   float dist = 0.f;
-  for (int i = 0; i < p.reg_max; ++i) dist += (expf(d[i] - m) / s) * (float)i;
+  if (p.reg_max == 16 && ((p.ld[l] & 1) == 0)) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) { const float2 t = *reinterpret_cast<const float2*>(d + i); v[i] = t.x; v[i + 1] = t.y; }
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, v[i]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dist += (v[i] / s) * (float)i;
+  } else {
+    float m = -INFINITY;
+    for (int i = 0; i < p.reg_max; ++i) m = fmaxf(m, d[i]);
+    float s = 0.f;
+    for (int i = 0; i < p.reg_max; ++i) s += expf(d[i] - m);
+    for (int i = 0; i < p.reg_max; ++i) dist += (expf(d[i] - m) / s) * (float)i;
+  }
 
   const int qbase = (threadIdx.x & 63) & ~3;
   const float dl = __shfl(dist, qbase + 0, 64), dt = __shfl(dist, qbase + 1, 64);
