@@ -93,6 +93,10 @@ def main():
     x = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(rank)).to(dev)  # resident in HBM
 
     def eager_step():
+        # drop-in forward(x, "infer") + decode / NMS / masks as one scheduled step (NMS forks under the Segment launches)
+        return model.infer_and_detect(x, IMG)[1]
+
+    def unfused_step():  # the same work as two plain calls: reference for the equality check below
         with torch.no_grad():
             out = model(x, "infer")
             feats, mc, protos = out["segment_protos"]
@@ -103,7 +107,7 @@ def main():
     else:
         # the same step (drop-in forward + post-process), captured once into a HIP graph and replayed
         graphed = GraphedInference(model, x, IMG)
-        ref = eager_step()
+        ref = unfused_step()
         torch.cuda.synchronize(dev)
         got = graphed.replay()
         torch.cuda.synchronize(dev)

@@ -107,9 +107,10 @@ class Plan:
         self.consts = []  # folded weights etc. (kept alive)
 
     # ---- execution ----
-    def run(self, stream: Optional[int] = None):
+    def run(self, stream: Optional[int] = None, start: int = 0, end: Optional[int] = None):
+        """Issue launches [start, end) on the current (or given) stream."""
         s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream)
-        for l in self.launches:
+        for l in self.launches[start:end]:
             rc = l.fn(*l.args, s)
             if rc != 0:
                 L.check(rc, l.name)

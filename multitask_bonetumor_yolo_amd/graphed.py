@@ -1,9 +1,9 @@
 """HIP-graph replay of the whole inference step (forward + decode + NMS + masks).
 
 The launch plan is ~220 short kernels; issued one by one from Python the host becomes visible between
-them.  `GraphedInference` captures one complete step -- `model(x, "infer")` followed by
-`postprocess.detect_and_segment` -- into a HIP graph on a private stream and replays it with a single
-call.  Inputs and outputs are static buffers: copy the next batch into `.x` (or construct with your own
+them.  `GraphedInference` captures one complete step -- `model.infer_and_detect` = `model(x, "infer")` +
+`postprocess.detect_and_segment`, with decode/NMS forked under the Segment/Proto launches -- into a HIP graph
+on a private stream and replays it with a single call.  Inputs and outputs are static buffers: copy the next batch into `.x` (or construct with your own
 resident buffer), call `replay()`, read `.out` (overwritten by the next replay).
 """
 import torch
@@ -19,6 +19,7 @@ class GraphedInference:
         self.model, self.x = model, x
         self.args = (img_size, conf_th, iou_th, top_k, masks)
         self.stream = torch.cuda.Stream(device=x.device)
+        self.side = torch.cuda.Stream(device=x.device)   # decode + NMS fork (see _Base.infer_and_detect)
         self.graph = torch.cuda.CUDAGraph()
         self.stream.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(self.stream), torch.no_grad():
@@ -31,10 +32,7 @@ class GraphedInference:
 
     def _step(self):
         img_size, conf_th, iou_th, top_k, masks = self.args
-        fwd = self.model(self.x, "infer")
-        feats, mc, protos = fwd["segment_protos"]
-        out = pp.detect_and_segment(fwd["detect_features"], mc, protos, img_size, conf_th, iou_th, top_k, masks)
-        return fwd, out
+        return self.model.infer_and_detect(self.x, img_size, conf_th, iou_th, top_k, masks, side_stream=self.side)
 
     def replay(self):
         self.graph.replay()

@@ -485,15 +485,16 @@ class _Base(nn.Module):
             n3, n4, n5 = lo.neck(c3, c4, c5)
             feats = [n3, n4, n5]
             det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
+            det_done = len(lo.p.launches)  # launches [0, det_done) produce the Detect maps: post-process can fork here
             seg_maps = lo.det_branch(feats, self.segment, "segment")
             mc, protos = lo.seg_extras(feats, self.segment)
             logits = lo.cls_head(n5)
         c = _Compiled(lo.p, xs, det_maps, seg_maps, mc, protos, logits, sig)
+        c.det_done = det_done if det_maps is not None else len(lo.p.launches)
         cache[key] = c
         return c
 
-    def _run(self, x: torch.Tensor) -> "_Compiled":
-        c = self.compile(x)
+    def _bind_input(self, c: "_Compiled", x: torch.Tensor):
         stem = c.plan.launches[0]
         if x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0:
             src = x            # read the caller's resident NCHW fp32 batch in place
@@ -502,6 +503,47 @@ class _Base(nn.Module):
             src = c.x
         stem.args = (src.data_ptr(),) + stem.args[1:]
         stem.keep = (src,) + tuple(stem.keep[1:])
+
+    @torch.no_grad()
+    def infer_and_detect(self, x: torch.Tensor, img_size: int, conf_th: float = 0.05, iou_th: float = 0.6, top_k: int = 100,
+                         masks: bool = True, side_stream: "torch.cuda.Stream" = None):
+        """`forward(x, "infer")` + `postprocess.detect_and_segment` as ONE scheduled step: the box decode and the
+        per-image NMS (16 workgroups of latency-bound work) fork onto a side stream as soon as the Detect maps exist and
+        run UNDER the Segment / Proto / cls launches; the mask assembly joins both.  Same results as the two calls.
+        Returns (forward dict, detections dict)."""
+        from . import postprocess as pp
+        det_flag, seg_flag = getattr(self, "detect", self.segment).training, self.segment.training
+        try:
+            if hasattr(self, "detect"):
+                self.detect.eval()
+            self.segment.eval()
+            c = self.compile(x)
+            self._bind_input(c, x)
+            maps = c.det_maps if c.det_maps is not None else c.seg_maps
+            main = torch.cuda.current_stream(x.device)
+            side = side_stream or self.__dict__.setdefault("_side_stream", torch.cuda.Stream(device=x.device))
+            c.plan.run(end=c.det_done)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                d = pp.decode_boxes([m.nchw() for m in maps], img_size, want_scores=False)
+                k = pp.nms_batched(d["boxes"], d["best_score"], d["best_label"], float(img_size), conf_th, iou_th, top_k)
+            c.plan.run(start=c.det_done)
+            main.wait_stream(side)
+            out = {"boxes": k["boxes"], "scores": k["scores"], "labels": k["labels"], "counts": k["counts"],
+                   "keep_idx": k["keep_idx"], "keep_anchor": k["keep_anchor"], "n_cand": k["n_cand"]}
+            if masks:
+                out["masks"], _ = pp.assemble_masks(c.protos.nchw(), c.mc.permute(0, 2, 1), k["keep_anchor"], k["counts"], (img_size, img_size))
+            for t in (d["boxes"], d["best_score"], d["best_label"]):
+                t.record_stream(main)
+            return self._infer_dict(c), out
+        finally:
+            if hasattr(self, "detect"):
+                self.detect.training = det_flag
+            self.segment.training = seg_flag
+
+    def _run(self, x: torch.Tensor) -> "_Compiled":
+        c = self.compile(x)
+        self._bind_input(c, x)
         c.plan.run()
         return c
 
@@ -513,6 +555,20 @@ class _Base(nn.Module):
 
 class ConvNeXtBiFPNYOLO(_Base):
     """Canonical variant, `/root/reference/src/main_model.py:300-393`."""
+
+    def _infer_dict(self, c):  # main_model.py:378-386
+        det_feats = [m.nchw().clone() for m in c.det_maps]
+        seg_feats = [m.nchw().clone() for m in c.seg_maps]
+        mc = c.mc.permute(0, 2, 1).clone()
+        logits = c.logits.clone()
+        return {
+            "detect_features": det_feats,
+            "detect_preds_cat": self._preds_cat(c.det_maps, self.detect),
+            "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
+            "segment_preds_cat": self._preds_cat(c.seg_maps, self.segment, c.mc),
+            "img_cls_logits": logits,
+            "img_cls_probs": logits.softmax(dim=1),
+        }
 
     def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32, bifpn_feature_size: int = 256,
                  bifpn_num_layers: int = 2, pretrained_backbone: bool = True):
@@ -540,19 +596,7 @@ class ConvNeXtBiFPNYOLO(_Base):
             if mode == "infer":      # main_model.py:367-386
                 self.detect.eval()
                 self.segment.eval()
-                c = self._run(x)
-                det_feats = [m.nchw().clone() for m in c.det_maps]
-                seg_feats = [m.nchw().clone() for m in c.seg_maps]
-                mc = c.mc.permute(0, 2, 1).clone()
-                logits = c.logits.clone()
-                return {
-                    "detect_features": det_feats,
-                    "detect_preds_cat": self._preds_cat(c.det_maps, self.detect),
-                    "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
-                    "segment_preds_cat": self._preds_cat(c.seg_maps, self.segment, c.mc),
-                    "img_cls_logits": logits,
-                    "img_cls_probs": logits.softmax(dim=1),
-                }
+                return self._infer_dict(self._run(x))
             raise ValueError(f"Unknown mode for ConvNeXtBiFPNYOLO.forward: {mode}. Expected 'train' or 'infer'.")
         finally:  # top-level flags only, as the reference does (main_model.py:391-393)
             self.detect.training = det_flag
@@ -561,6 +605,19 @@ class ConvNeXtBiFPNYOLO(_Base):
 
 class ConvNeXtBiFPNYOLOv2(_Base):
     """Segment-only variant, `/root/reference/src/main_modelv2.py:300-385`."""
+
+    def _infer_dict(self, c):  # main_modelv2.py:371-378
+        seg_feats = [m.nchw().clone() for m in c.seg_maps]
+        mc = c.mc.permute(0, 2, 1).clone()
+        seg_cat = self._preds_cat(c.seg_maps, self.segment, c.mc)
+        logits = c.logits.clone()
+        return {
+            "detect_preds_cat": seg_cat[:, : 4 + self.nc_det],
+            "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
+            "segment_preds_cat": seg_cat,
+            "img_cls_logits": logits,
+            "img_cls_probs": logits.softmax(dim=1),
+        }
 
     def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32, bifpn_feature_size: int = 256,
                  bifpn_num_layers: int = 2, pretrained_backbone: bool = True):
@@ -584,18 +641,7 @@ class ConvNeXtBiFPNYOLOv2(_Base):
                 return (seg, c.mc.permute(0, 2, 1).clone(), c.protos.nchw().clone()), c.logits.clone()
             if mode == "infer":      # main_modelv2.py:362-378
                 self.segment.eval()
-                c = self._run(x)
-                seg_feats = [m.nchw().clone() for m in c.seg_maps]
-                mc = c.mc.permute(0, 2, 1).clone()
-                seg_cat = self._preds_cat(c.seg_maps, self.segment, c.mc)
-                logits = c.logits.clone()
-                return {
-                    "detect_preds_cat": seg_cat[:, : 4 + self.nc_det],
-                    "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
-                    "segment_preds_cat": seg_cat,
-                    "img_cls_logits": logits,
-                    "img_cls_probs": logits.softmax(dim=1),
-                }
+                return self._infer_dict(self._run(x))
             raise ValueError(f"Unknown mode for ConvNeXtBiFPNYOLO.forward: {mode}. Expected 'train' or 'infer'.")
         finally:
             self.segment.training = seg_flag
