@@ -132,7 +132,8 @@ def main():
             return "1x1 other"
         for rnd in range(2):
             for pol in args.ab.split(","):
-                os.environ["MTBT_CONV_POLICY"] = pol
+                var, _, val = pol.rpartition("=")
+                os.environ[var or "MTBT_CONV_POLICY"] = val
                 model.__dict__.pop("_plans", None)
                 c = model.compile(x)
                 c.plan.run(); c.plan.run()
@@ -141,7 +142,8 @@ def main():
                 for l, t in zip(c.plan.launches, ms):
                     agg[cat(l.name)] = agg.get(cat(l.name), 0.0) + t
                 print(f"policy {pol} round {rnd}: total {sum(ms):.3f} ms | " + " ".join(f"{k}={v*1e3:.0f}" for k, v in agg.items()), file=sys.stderr)
-        os.environ.pop("MTBT_CONV_POLICY", None)
+        for pol in args.ab.split(","):
+            os.environ.pop(pol.rpartition("=")[0] or "MTBT_CONV_POLICY", None)
         model.__dict__.pop("_plans", None)
     if rank == 0:
         # ---- roofline of the dominant kernel family: instrumented replay of the same plan ----

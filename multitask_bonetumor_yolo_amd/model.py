@@ -292,6 +292,18 @@ class _Lowering:
         self.p.conv(x, self.W(pw * scale[:, None]), y, shift=self.F(shift), act=L.ACT_ELU, name=name)
         return y
 
+    def subbatch(self, stage: int, a: Act) -> int:
+        """Images per depth-first pass of a ConvNeXt stage.  Measured (bench.py --ab MTBT_SUBBATCH=...): keeping the 4d-wide
+        intermediate Infinity-Cache-resident by running 2-8 images at a time does NOT pay on MI355X at batch 16 -- the
+        smaller launches lose more to ramp/tail than the cache saves (9.75 ms at 4:8 vs 9.46 ms whole-batch) -- so the
+        default is the whole batch; MTBT_SUBBATCH="s0:s1:s2:s3" overrides for experiments."""
+        import os
+        env = os.environ.get("MTBT_SUBBATCH")
+        if env:
+            v = int(env.split(":")[stage])
+            return a.N if v <= 0 else min(v, a.N)
+        return a.N
+
     # -- backbone (main_model.py:33-38) --
     def backbone(self):
         bb = self.m.backbone
@@ -315,21 +327,37 @@ class _Lowering:
                     self.p.release(a)
                 a = nxt
             d = a.C
-            for bi, blk in enumerate(st.blocks):
-                bn_ = f"{nm}.blocks.{bi}"
-                t = self.p.new(a.N, a.H, a.W, d, self.code)
-                self.p.dwconv(a, self.W(blk.conv_dw.weight.detach().reshape(d, 49).t()), t, 7, bias=self.F(blk.conv_dw.bias),
-                              lnw=self.F(blk.norm.weight), lnb=self.F(blk.norm.bias), eps=blk.norm.eps, name=bn_ + ".conv_dw+norm")
-                h = self.p.new(a.N, a.H, a.W, 4 * d, self.code)
-                self.p.conv(t, self.W(blk.mlp.fc1.weight), h, shift=self.F(blk.mlp.fc1.bias), act=L.ACT_GELU, name=bn_ + ".mlp.fc1")
-                self.p.release(t)
-                o = self.p.new(a.N, a.H, a.W, d, self.code)
+            # Sub-batching (depth-first over the stage's blocks): the 4d-wide MLP intermediate of a full batch does not fit
+            # the 256 MiB Infinity Cache in the early stages (16 x 160^2 x 384 bf16 = 315 MB); running all blocks of the
+            # stage on a few images at a time keeps t / h / o cache-resident instead of round-tripping through HBM.
+            sb = self.subbatch(si, a)
+            out_full = self.p.new(a.N, a.H, a.W, d, self.code)
+            t = self.p.new(sb, a.H, a.W, d, self.code)
+            h = self.p.new(sb, a.H, a.W, 4 * d, self.code)
+            pp_ = [self.p.new(sb, a.H, a.W, d, self.code) for _ in range(2)] if len(st.blocks) > 1 else []
+            consts = []
+            for blk in st.blocks:
                 g = blk.gamma.detach().float()
-                self.p.conv(h, self.W(blk.mlp.fc2.weight.detach().float() * g[:, None]), o,
-                            shift=self.F(g * blk.mlp.fc2.bias.detach().float()), res=a, name=bn_ + ".mlp.fc2")
-                self.p.release(h)
-                self.p.release(a)    # block input: stem / downsample / previous block output, never a feature
-                a = o
+                consts.append((self.W(blk.conv_dw.weight.detach().reshape(d, 49).t()), self.F(blk.conv_dw.bias), self.F(blk.norm.weight),
+                               self.F(blk.norm.bias), self.W(blk.mlp.fc1.weight), self.F(blk.mlp.fc1.bias),
+                               self.W(blk.mlp.fc2.weight.detach().float() * g[:, None]), self.F(g * blk.mlp.fc2.bias.detach().float())))
+            for n0 in range(0, a.N, sb):
+                nn_ = min(sb, a.N - n0)
+                view = lambda act, k=nn_, o=n0: Act(act.buf, act.off + o * act.bs, k, act.H, act.W, act.C, act.ld, act.bs)
+                local = lambda act, k=nn_: Act(act.buf, act.off, k, act.H, act.W, act.C, act.ld, act.bs)
+                cur = view(a)
+                for bi, blk in enumerate(st.blocks):
+                    bn_ = f"{nm}.blocks.{bi}" + (f"[{n0}:{n0 + nn_}]" if sb < a.N else "")
+                    dww, dwb, lnw, lnb, w1, b1, w2, b2 = consts[bi]
+                    self.p.dwconv(cur, dww, local(t), 7, bias=dwb, lnw=lnw, lnb=lnb, eps=blk.norm.eps, name=bn_ + ".conv_dw+norm")
+                    self.p.conv(local(t), w1, local(h), shift=b1, act=L.ACT_GELU, name=bn_ + ".mlp.fc1")
+                    dst = view(out_full) if bi == len(st.blocks) - 1 else local(pp_[bi % 2])
+                    self.p.conv(local(h), w2, dst, shift=b2, res=cur, name=bn_ + ".mlp.fc2")
+                    cur = dst
+            for buf in [t, h] + pp_:
+                self.p.release(buf)
+            self.p.release(a)        # stage input: stem / downsample output, never a feature
+            a = out_full
             if si >= 1:
                 feats.append(a)      # stage outputs 1..3 stay live until the adaptors have read them
         c3 = self.c2f(feats[0], bb.c2f_p3, "backbone.c2f_p3")
