@@ -127,6 +127,19 @@ typedef struct mtbt_fuse_args {
 
 int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d forward with BATCH statistics + activation (module in train mode): the reference flips the
+ * Detect/Segment heads to train mode inside forward(mode="train") (main_model.py:358-359), so their
+ * BatchNorms use batch statistics and update running_mean/var (momentum, unbiased variance) -- SURVEY F14.
+ *   y = act((x - mean_batch) / sqrt(var_batch + eps) * gamma + beta);  x, y dense NHWC [pixels][C] (y may alias x).
+ * Deterministic two-pass statistics.  workspace >= mtbt_bn_train_workspace_bytes(pixels, C); on return its
+ * last 2*C floats hold (mean, biased var).  running_mean / running_var may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int64_t mtbt_bn_train_workspace_bytes(int64_t pixels, int C);
+int mtbt_bn_train_nhwc(const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Global average pool over H*W then Linear(C, nout) (main_model.py:333-334, :364). y [N,nout] f32. */
 int mtbt_gap_fc(const void* x, const float* w, const float* b, float* y, int N, int HW, int C,
                 int nout, int dtype, void* stream);

@@ -65,6 +65,9 @@ SYMBOLS = {
                          + [C.c_int] * 6 + [C.c_void_p]),
     "mtbt_layernorm_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_bifpn_fuse": (C.c_int, [C.POINTER(FuseArgs), C.c_void_p]),
+    "mtbt_bn_train_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "mtbt_bn_train_nhwc": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_int64, C.c_void_p]),
     "mtbt_gap_fc": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "mtbt_decode_boxes": (C.c_int, [C.POINTER(DecodeArgs), C.c_void_p]),
     "mtbt_nms_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),

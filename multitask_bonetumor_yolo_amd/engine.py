@@ -213,5 +213,27 @@ class Plan:
         self.launches.append(Launch(self.lib.mtbt_gap_fc, args, name, (x.buf, w, b, y), 0.0,
                                     x.N * x.H * x.W * x.C * ESIZE[x.code]))
 
+    def bn_train(self, x: Act, y: Act, bn, act, name="bn_train"):
+        """BatchNorm with batch statistics + activation over a dense NHWC tensor; updates bn.running_* in place."""
+        assert x.dense and y.dense and x.C == y.C and x.code == y.code
+        if bn.momentum is None:
+            raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not supported")
+        pixels = x.N * x.H * x.W
+        nbytes = self.lib.mtbt_bn_train_workspace_bytes(pixels, x.C)
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=self.device)
+        rm = bn.running_mean.data_ptr() if bn.running_mean is not None else None
+        rv = bn.running_var.data_ptr() if bn.running_var is not None else None
+        g, b = self.const(bn.weight, torch.float32), self.const(bn.bias, torch.float32)
+        args = (x.ptr, y.ptr, g.data_ptr(), b.data_ptr(), rm, rv, C.c_float(bn.momentum), C.c_float(bn.eps), act, pixels, x.C,
+                x.code, ws.data_ptr(), nbytes)
+        self.launches.append(Launch(self.lib.mtbt_bn_train_nhwc, args, name, (x.buf, y.buf, g, b, ws, bn), 0.0,
+                                    3.0 * pixels * x.C * ESIZE[x.code]))
+
+    def cast(self, x: Act, y: Act, name="cast"):
+        assert x.dense and y.dense
+        n = x.N * x.H * x.W * x.C
+        self.launches.append(Launch(self.lib.mtbt_cast, (x.ptr, y.ptr, n, x.code, y.code), name, (x.buf, y.buf), 0.0,
+                                    n * (ESIZE[x.code] + ESIZE[y.code])))
+
     def raw(self, fn, args, name, keep=()):
         self.launches.append(Launch(fn, args, name, keep))

@@ -220,6 +220,7 @@ class _Lowering:
         self.dt = TORCH_DTYPE[code]
         self.p = Plan(x.device)
         self.x = x
+        self.train_bns = []  # BatchNorms lowered with batch statistics (their num_batches_tracked advances per run)
 
     # constants
     def W(self, t):  # weights in compute dtype
@@ -228,19 +229,34 @@ class _Lowering:
     def F(self, t):  # fp32 vectors
         return self.p.const(t.float(), torch.float32)
 
-    @staticmethod
-    def _need_eval(bn, where):
-        if bn.training:
-            raise NotImplementedError(
-                f"{where}: BatchNorm in train mode (batch statistics) is not lowered to HIP yet; use model.eval() "
-                "and mode='infer' (see DESIGN.md, scope)")
+    def _bn_batch_stats(self, raw: Act, bn, act, y, name):
+        """BatchNorm in train mode (batch statistics, running-stat update) + activation on the raw conv output."""
+        if y is not None and not y.dense:
+            raise NotImplementedError(f"{name}: batch-statistic BatchNorm into a channel slice (C2f concat buffer) is not lowered; "
+                                      "only the Detect/Segment heads run in train mode inside forward(mode='train')")
+        self.train_bns.append(bn)
+        if y is None or y.code == raw.code:
+            out = y if y is not None else raw            # in place unless the caller owns the destination
+            self.p.bn_train(raw, out, bn, act, name=name + ".bn(batch)")
+            if out is not raw:
+                self.p.release(raw)
+            return out
+        self.p.bn_train(raw, raw, bn, act, name=name + ".bn(batch)")
+        self.p.cast(raw, y, name=name + ".cast")          # e.g. the fp32 prototype output in bf16 mode
+        self.p.release(raw)
+        return y
 
     # -- building blocks --
     def convblock(self, x: Act, mod, y: Act = None, name=""):
-        """reference ConvBlock (conv bias) or ultralytics Conv (no bias): conv + BN(eval) + SiLU."""
+        """reference ConvBlock (conv bias) or ultralytics Conv (no bias): conv + BN + SiLU.  BN in eval mode folds into
+        the weights / epilogue shift; BN in train mode (heads inside forward(mode="train")) uses batch statistics."""
         conv, bn = mod.conv, mod.bn
-        self._need_eval(bn, name)
         k = conv.kernel_size[0]
+        if bn.training:
+            raw = self.p.new(x.N, x.H, x.W, conv.out_channels, self.code)
+            self.p.conv(x, self.W(_krsc(conv.weight)), raw, R=k, S=k, stride=1, pad=k // 2,
+                        shift=self.F(conv.bias) if conv.bias is not None else None, name=name)
+            return self._bn_batch_stats(raw, bn, L.ACT_SILU, y, name)
         scale, shift = _bn_fold(bn, conv.bias)
         if y is None:
             y = self.p.new(x.N, x.H, x.W, conv.out_channels, self.code)
@@ -257,10 +273,13 @@ class _Lowering:
 
     def dwblock(self, x: Act, mod: _UConv, name=""):
         """ultralytics DWConv: depthwise 3x3 + BN + SiLU."""
-        self._need_eval(mod.bn, name)
-        scale, shift = _bn_fold(mod.bn)
         w = self.W(mod.conv.weight.detach().reshape(x.C, 9).t())
         y = self.p.new(x.N, x.H, x.W, x.C, self.code)
+        if mod.bn.training:
+            one, zero = self.F(torch.ones(x.C)), self.F(torch.zeros(x.C))
+            self.p.dwconv(x, w, y, 3, scale=one, shift=zero, act=L.ACT_NONE, name=name)
+            return self._bn_batch_stats(y, mod.bn, L.ACT_SILU, None, name)
+        scale, shift = _bn_fold(mod.bn)
         self.p.dwconv(x, w, y, 3, scale=self.F(scale), shift=self.F(shift), act=L.ACT_SILU, name=name)
         return y
 
@@ -284,7 +303,8 @@ class _Lowering:
 
     def dw_pointwise(self, x: Act, mod: DepthwiseConvBlock, name=""):
         """DepthwiseConvBlock (k=1): per-channel scale folded into the pointwise weight, BN folded, ELU."""
-        self._need_eval(mod.bn, name)
+        if mod.bn.training:
+            raise NotImplementedError(f"{name}: BiFPN DepthwiseConvBlock with batch-statistic BatchNorm (model.train()) is not lowered yet")
         dw = mod.depthwise.weight.detach().float().reshape(1, -1)
         pw = mod.pointwise.weight.detach().float().reshape(mod.pointwise.out_channels, -1) * dw
         scale, shift = _bn_fold(mod.bn)
@@ -489,7 +509,7 @@ class _Base(nn.Module):
 
     def _weights_sig(self):
         return (sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
-                tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)))
+                tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)), self.__dict__.get("_bn_epoch", 0))
 
     def _heads(self):
         raise NotImplementedError
@@ -519,6 +539,7 @@ class _Base(nn.Module):
             logits = lo.cls_head(n5)
         c = _Compiled(lo.p, xs, det_maps, seg_maps, mc, protos, logits, sig)
         c.det_done = det_done if det_maps is not None else len(lo.p.launches)
+        c.train_bns = lo.train_bns
         cache[key] = c
         return c
 
@@ -573,7 +594,16 @@ class _Base(nn.Module):
         c = self.compile(x)
         self._bind_input(c, x)
         c.plan.run()
+        self._after_run(c)
         return c
+
+    def _after_run(self, c):
+        """Book-keeping of batch-statistic BatchNorms: the kernels updated running_mean / running_var in place."""
+        if c.train_bns:
+            for bn in c.train_bns:
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+            self.__dict__["_bn_epoch"] = self.__dict__.get("_bn_epoch", 0) + 1  # invalidates plans that folded the old statistics
 
     # decoded `[B, 4+nc(+nm), A]` tensor of Detect/Segment eval (ultralytics `_inference`), from raw maps
     def _preds_cat(self, maps: List[Act], head: Detect, mc: torch.Tensor = None):

@@ -131,6 +131,59 @@ def test_postprocess_pipeline_on_model_outputs(pair):
         assert torch.allclose(d["boxes"][b].cpu(), boxes[b], rtol=1e-5, atol=1e-3)
 
 
+def test_train_mode_forward_batch_stat_heads():
+    """forward(x, "train") under model.eval(): the reference flips the heads to train mode (main_model.py:358-359), so
+    their BatchNorms use batch statistics and update the running statistics.  Fresh pair: state mutates."""
+    torch.manual_seed(3)
+    ora = randomize_(OracleModel(2, 2, pretrained_backbone=False)).eval()
+    hip = ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.to(DEV).eval().set_compute_dtype(torch.float32)
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        rdet, (rseg, rmc, rprotos), rlog = ora(x, "train")
+        det, (seg, mc, protos), log = hip(x.to(DEV), "train")
+    torch.cuda.synchronize()
+    assert len(det) == 3 and len(seg) == 3
+    for o, r in zip(list(det) + list(seg), list(rdet) + list(rseg)):
+        assert o.shape == r.shape and maxdiff(o, r) < 1e-3
+    assert mc.shape == rmc.shape and maxdiff(mc, rmc) < 1e-3
+    assert protos.shape == rprotos.shape and maxdiff(protos, rprotos) < 1e-3
+    assert maxdiff(log, rlog) < 1e-3
+    # flag handling (F14): top-level flags restored, children left in train mode; running statistics advanced identically
+    assert hip.detect.training is False and hip.segment.training is False
+    assert hip.detect.cv2[0][0].bn.training and ora.detect.cv2[0][0].bn.training
+    hsd, osd = hip.state_dict(), ora.state_dict()
+    for k in osd:
+        if "running_" in k or "num_batches_tracked" in k:
+            assert maxdiff(hsd[k], osd[k].float()) < 1e-4, k
+    assert int(hsd["segment.proto.cv2.bn.num_batches_tracked"]) == 1
+    # a following infer call must use the UPDATED running statistics (plans that folded the old ones are invalidated)
+    with torch.no_grad():
+        ri = ora(x, "infer")
+        hi = hip(x.to(DEV), "infer")
+    torch.cuda.synchronize()
+    for o, r in zip(hi["detect_features"], ri["detect_features"]):
+        assert maxdiff(o, r) < 1e-3
+    assert maxdiff(hi["segment_protos"][2], ri["segment_protos"][2]) < 1e-3
+
+
+def test_train_mode_forward_bf16_and_v2():
+    torch.manual_seed(5)
+    ora = randomize_(OracleModelV2(2, 2, pretrained_backbone=False)).eval()
+    hip = ConvNeXtBiFPNYOLOv2(2, 2, pretrained_backbone=False)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        (rseg, rmc, rprotos), rlog = ora(x, "train")
+        (seg, mc, protos), log = hip(x.to(DEV), "train")
+    torch.cuda.synchronize()
+    for o, r in zip(seg, rseg):
+        assert o.shape == r.shape and relerr(o, r) < 6e-2
+    assert relerr(mc, rmc) < 6e-2 and relerr(protos, rprotos) < 6e-2
+
+
 def test_v2_variant_layout():
     torch.manual_seed(1)
     ora = randomize_(OracleModelV2(2, 3, pretrained_backbone=False)).eval()
