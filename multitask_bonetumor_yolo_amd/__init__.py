@@ -8,4 +8,4 @@ The HIP library (csrc/libmtbt_hip.so, C ABI in include/mtbt_hip.h) is built by
 """
 from . import postprocess  # noqa: F401
 from .graphed import GraphedInference  # noqa: F401
-from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv2, init_synthetic_  # noqa: F401
+from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv0, ConvNeXtBiFPNYOLOv2, init_synthetic_  # noqa: F401

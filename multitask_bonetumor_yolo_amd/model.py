@@ -327,7 +327,16 @@ class _Lowering:
     # -- backbone (main_model.py:33-38) --
     def backbone(self):
         bb = self.m.backbone
-        body = bb.body
+        feats = self.features(bb.body)
+        c3 = self.c2f(feats[0], bb.c2f_p3, "backbone.c2f_p3")
+        c4 = self.c2f(feats[1], bb.c2f_p4, "backbone.c2f_p4")
+        c5 = self.c2f(feats[2], bb.c2f_p5, "backbone.c2f_p5")
+        for f in feats:
+            self.p.release(f)
+        return c3, c4, c5
+
+    def features(self, body):
+        """timm ConvNeXt-T feature extractor: outputs of stages 1..3 (live buffers; the caller releases them)."""
         N, _, H, W = self.x.shape
         a = self.p.new(N, H // 4, W // 4, DIMS[0], self.code)
         self.p.stem(self.x, self.F(body.stem_0.weight.detach().reshape(DIMS[0], 48)), self.F(body.stem_0.bias),
@@ -380,12 +389,36 @@ class _Lowering:
             a = out_full
             if si >= 1:
                 feats.append(a)      # stage outputs 1..3 stay live until the adaptors have read them
-        c3 = self.c2f(feats[0], bb.c2f_p3, "backbone.c2f_p3")
-        c4 = self.c2f(feats[1], bb.c2f_p4, "backbone.c2f_p4")
-        c5 = self.c2f(feats[2], bb.c2f_p5, "backbone.c2f_p5")
-        for f in feats:
-            self.p.release(f)
-        return c3, c4, c5
+        return feats
+
+    # -- neck of the oldest variant (src/model.py:27-93): lateral Convs, WeightedAdd (adds its weights), DWConv 3x3 nodes --
+    def neck_v0(self, f3, f4, f5):
+        nk = self.m.neck
+        p3 = self.convblock(f3, nk.lat3, None, "neck.lat3")
+        p4 = self.convblock(f4, nk.lat4, None, "neck.lat4")
+        p5 = self.convblock(f5, nk.lat5, None, "neck.lat5")
+        for t in (f3, f4, f5):
+            self.p.release(t)
+        for ui, u in enumerate(nk.units):
+            nm = f"neck.units.{ui}"
+
+            def node(add, inputs, modes, like: Act, key):
+                w = torch.relu(add.w.detach().float().cpu())
+                w = w / (w.sum() + add.eps)
+                s_ = self.p.new(like.N, like.H, like.W, like.C, self.code)
+                self.p.fuse(inputs, [float(v) for v in w], modes, s_, bug=True, name=f"{nm}.add_{key}")
+                o = self.dwblock(s_, u.conv[key], f"{nm}.conv.{key}")
+                self.p.release(s_)
+                return o
+
+            p4_td = node(u.add_p4_td, [p4, p5], [L.RES_ID, L.RES_UP_NEAREST], p4, "p4_td")
+            p3_td = node(u.add_p3_td, [p3, p4_td], [L.RES_ID, L.RES_UP_NEAREST], p3, "p3_td")
+            p4_out = node(u.add_p4_out, [p4, p4_td, p3_td], [L.RES_ID, L.RES_ID, L.RES_MAXPOOL], p4, "p4_out")
+            p5_out = node(u.add_p5_out, [p5, p4_out], [L.RES_ID, L.RES_MAXPOOL], p5, "p5_out")
+            for t in (p3, p4, p5, p4_td):
+                self.p.release(t)
+            p3, p4, p5 = p3_td, p4_out, p5_out
+        return p3, p4, p5
 
     # -- neck (main_model.py:198-243, 275-296) --
     @staticmethod
@@ -529,8 +562,11 @@ class _Base(nn.Module):
         with torch.no_grad():
             xs = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
             lo = _Lowering(self, xs, code_of(self.compute_dtype))
-            c3, c4, c5 = lo.backbone()
-            n3, n4, n5 = lo.neck(c3, c4, c5)
+            if isinstance(self, ConvNeXtBiFPNYOLOv0):
+                n3, n4, n5 = lo.neck_v0(*lo.features(self.backbone.body))
+            else:
+                c3, c4, c5 = lo.backbone()
+                n3, n4, n5 = lo.neck(c3, c4, c5)
             feats = [n3, n4, n5]
             det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
             det_done = len(lo.p.launches)  # launches [0, det_done) produce the Detect maps: post-process can fork here
@@ -703,6 +739,68 @@ class ConvNeXtBiFPNYOLOv2(_Base):
             raise ValueError(f"Unknown mode for ConvNeXtBiFPNYOLO.forward: {mode}. Expected 'train' or 'infer'.")
         finally:
             self.segment.training = seg_flag
+
+
+class _WeightedAdd(_Params):
+    def __init__(self, n, eps=1e-4):
+        super().__init__()
+        self.w = nn.Parameter(torch.ones(n, dtype=torch.float32))
+        self.eps = eps
+
+
+class _BiFPNUnitV0(_Params):
+    def __init__(self, ch=256):
+        super().__init__()
+        self.add_p4_td, self.add_p3_td = _WeightedAdd(2), _WeightedAdd(2)
+        self.add_p4_out, self.add_p5_out = _WeightedAdd(3), _WeightedAdd(2)
+        self.conv = nn.ModuleDict({k: _UConv(ch, ch, 3, g=ch) for k in ("p4_td", "p3_td", "p4_out", "p5_out")})
+
+
+class _BiFPNV0(_Params):
+    def __init__(self, in_ch, repeats=2):
+        super().__init__()
+        self.lat3, self.lat4, self.lat5 = _UConv(in_ch[0], 256, 1), _UConv(in_ch[1], 256, 1), _UConv(in_ch[2], 256, 1)
+        self.units = nn.ModuleList([_BiFPNUnitV0(256) for _ in range(repeats)])
+
+
+class _BackboneV0(_Params):
+    def __init__(self):
+        super().__init__()
+        self.body = _CNFeatures()
+        self.out_channels = list(DIMS[1:])
+
+
+class ConvNeXtBiFPNYOLOv0(_Base):
+    """Oldest variant, `/root/reference/src/model.py:97-123` (BASELINE config 0): ConvNeXt-T features -> BiFPN with
+    lateral Convs / nearest-x2 / max-pool / DWConv 3x3 nodes and the weight-ADDING WeightedAdd ->
+    Detect + Segment + cls.  `forward(x, mode="infer")` does not touch the heads' training flags; this build lowers the
+    eval state (module.eval()), i.e. `{"detect": (y, feats), "segment": (cat[y, mc], (feats, mc, protos)), "img_cls": softmax}`
+    or, for any other mode, the raw `(det_out, seg_out, logits)` tuple."""
+
+    def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32):
+        super().__init__()
+        L.load()
+        self.backbone = _BackboneV0()
+        self.neck = _BiFPNV0(self.backbone.out_channels, repeats=2)
+        ch = (256, 256, 256)
+        self.detect = Detect(nc_det, ch=ch)
+        self.segment = Segment(nc_det, nm=proto_ch, ch=ch)
+        self.cls_pool = nn.AdaptiveAvgPool2d(1)
+        self.cls_fc = nn.Linear(256, nc_img)
+
+    def forward(self, x, mode: str = "infer"):
+        if self.detect.training or self.segment.training or any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
+            raise NotImplementedError("the src/model.py variant is lowered for module.eval() only")
+        c = self._run(x)
+        det_feats = [m.nchw().clone() for m in c.det_maps]
+        seg_feats = [m.nchw().clone() for m in c.seg_maps]
+        mc = c.mc.permute(0, 2, 1).clone()
+        det_out = (self._preds_cat(c.det_maps, self.detect), det_feats)
+        seg_out = (self._preds_cat(c.seg_maps, self.segment, c.mc), (seg_feats, mc, c.protos.nchw().clone()))
+        logits = c.logits.clone()
+        if mode == "infer":
+            return {"detect": det_out, "segment": (seg_out[0], seg_out[1]), "img_cls": logits.softmax(1)}
+        return det_out, seg_out, logits
 
 
 @torch.no_grad()

@@ -135,3 +135,97 @@ def randomize_(model: nn.Module, seed: int = 0) -> nn.Module:
         elif name.endswith(".w1") or name.endswith(".w2"):
             p.fill_(1.0)
     return model
+
+
+# ---------------------------------------------------------------------------------------------------
+# Oldest variant: /root/reference/src/model.py (BASELINE config 0).  ConvNeXt-T features straight into a
+# BiFPN with ultralytics lateral Convs, DWConv 3x3 nodes, nearest-x2 / max-pool resampling and the
+# WeightedAdd that ADDS its weights (`sum(w_i + f)`, src/model.py:33-36).
+# ---------------------------------------------------------------------------------------------------
+import torch.nn.functional as _F
+
+from .heads import Conv as _UConv, DWConv as _UDWConv
+
+
+class WeightedAdd(nn.Module):
+    def __init__(self, n, eps=1e-4):
+        super().__init__()
+        self.w = nn.Parameter(torch.ones(n, dtype=torch.float32))
+        self.eps = eps
+
+    def forward(self, feats):
+        w = _F.relu(self.w)
+        w = w / (w.sum() + self.eps)
+        return sum(w_i + f for w_i, f in zip(w, feats))  # sic: adds the weight (src/model.py:36)
+
+
+class BiFPNUnitV0(nn.Module):
+    """src/model.py:39-71."""
+
+    def __init__(self, ch=256):
+        super().__init__()
+        self.add_p4_td = WeightedAdd(2)
+        self.add_p3_td = WeightedAdd(2)
+        self.add_p4_out = WeightedAdd(3)
+        self.add_p5_out = WeightedAdd(2)
+        self.conv = nn.ModuleDict({k: _UDWConv(ch, ch, k=3, s=1) for k in ("p4_td", "p3_td", "p4_out", "p5_out")})
+
+    def forward(self, p3, p4, p5):
+        p4_td = self.conv["p4_td"](self.add_p4_td([p4, _F.interpolate(p5, scale_factor=2, mode="nearest")]))
+        p3_td = self.conv["p3_td"](self.add_p3_td([p3, _F.interpolate(p4_td, scale_factor=2, mode="nearest")]))
+        p4_out = self.conv["p4_out"](self.add_p4_out([p4, p4_td, _F.max_pool2d(p3_td, 2)]))
+        p5_out = self.conv["p5_out"](self.add_p5_out([p5, _F.max_pool2d(p4_out, 2)]))
+        return p3_td, p4_out, p5_out
+
+
+class BiFPNV0(nn.Module):
+    """src/model.py:74-93."""
+
+    def __init__(self, in_ch=(96, 192, 384), repeats=2):
+        super().__init__()
+        self.lat3 = _UConv(in_ch[0], 256, 1, 1)
+        self.lat4 = _UConv(in_ch[1], 256, 1, 1)
+        self.lat5 = _UConv(in_ch[2], 256, 1, 1)
+        self.units = nn.ModuleList([BiFPNUnitV0(256) for _ in range(repeats)])
+
+    def forward(self, feats):
+        p3, p4, p5 = feats
+        p3, p4, p5 = self.lat3(p3), self.lat4(p4), self.lat5(p5)
+        for layer in self.units:
+            p3, p4, p5 = layer(p3, p4, p5)
+        return p3, p4, p5
+
+
+class _BackboneV0(nn.Module):
+    """src/model.py:13-23 (timm features only; `pretrained=True` there would need the network)."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = ConvNeXtTinyFeatures()
+        self.out_channels = self.body.channels()
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class ConvNeXtBiFPNYOLOv0(nn.Module):
+    """src/model.py:97-123."""
+
+    def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32):
+        super().__init__()
+        self.backbone = _BackboneV0()
+        self.neck = BiFPNV0(self.backbone.out_channels, repeats=2)
+        ch = (256, 256, 256)
+        self.detect = Detect(nc_det, ch=ch)
+        self.segment = Segment(nc_det, nm=proto_ch, ch=ch)
+        self.cls_pool = nn.AdaptiveAvgPool2d(1)
+        self.cls_fc = nn.Linear(256, nc_img)
+
+    def forward(self, x, mode: str = "infer"):
+        p3, p4, p5 = self.neck(self.backbone(x))
+        det_out = self.detect([p3, p4, p5])
+        seg_out = self.segment([p3, p4, p5])
+        img_logits = self.cls_fc(self.cls_pool(p5).flatten(1))
+        if mode == "infer":
+            return {"detect": det_out, "segment": (seg_out[0], seg_out[1]), "img_cls": img_logits.softmax(1)}
+        return det_out, seg_out, img_logits

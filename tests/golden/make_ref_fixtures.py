@@ -127,6 +127,18 @@ def main():
         cases["dist2bbox_xywh"] = {"inputs": (d, a), "output": ref_train.dist2bbox(d, a, "xywh")}
         cases["constants"] = {"CONF_TH": ref_train.CONF_TH, "NMS_IOU": ref_train.NMS_IOU, "TOP_K": ref_train.TOP_K}
 
+    # src/model.py (oldest variant): WeightedAdd is pure torch and ADDS its weights
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_model_v0", os.path.join(REF_SRC, "model.py"))
+    v0 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(v0)
+    for n in (2, 3):
+        wa = v0.WeightedAdd(n)
+        with torch.no_grad():
+            wa.w.copy_(torch.rand(n, generator=gen) + 0.25)
+            feats = [r(2, 8, 6, 5) for _ in range(n)]
+            cases[f"WeightedAdd_{n}"] = {"w": wa.w.detach().clone(), "inputs": feats, "output": wa(feats).clone()}
+
     torch.save(cases, OUT)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", list(cases))
 

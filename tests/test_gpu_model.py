@@ -184,6 +184,36 @@ def test_train_mode_forward_bf16_and_v2():
     assert relerr(mc, rmc) < 6e-2 and relerr(protos, rprotos) < 6e-2
 
 
+def test_v0_variant_src_model_py():
+    """BASELINE config 0: the `src/model.py` variant (nearest / max-pool BiFPN, DWConv nodes, weight-adding WeightedAdd)."""
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLOv0
+    from oracle.model import ConvNeXtBiFPNYOLOv0 as OracleModelV0
+    torch.manual_seed(7)
+    ora = randomize_(OracleModelV0(3, 3)).eval()
+    with torch.no_grad():
+        for u in ora.neck.units:  # non-trivial fusion weights
+            for a in (u.add_p4_td, u.add_p3_td, u.add_p4_out, u.add_p5_out):
+                a.w.copy_(torch.rand_like(a.w) + 0.2)
+    hip = ConvNeXtBiFPNYOLOv0(3, 3)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.to(DEV).eval().set_compute_dtype(torch.float32)
+    x = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        ref = ora(x)
+        out = hip(x.to(DEV))
+    torch.cuda.synchronize()
+    assert set(out) == {"detect", "segment", "img_cls"}
+    assert maxdiff(out["detect"][0], ref["detect"][0]) < 1e-3
+    for o, r in zip(out["detect"][1], ref["detect"][1]):
+        assert o.shape == r.shape and maxdiff(o, r) < 1e-3
+    assert maxdiff(out["segment"][0], ref["segment"][0]) < 1e-3
+    feats, mc, protos = out["segment"][1]
+    assert maxdiff(mc, ref["segment"][1][1]) < 1e-3 and maxdiff(protos, ref["segment"][1][2]) < 1e-3
+    assert maxdiff(out["img_cls"], ref["img_cls"]) < 1e-3
+    raw = hip(x.to(DEV), mode="raw")
+    assert isinstance(raw, tuple) and len(raw) == 3
+
+
 def test_v2_variant_layout():
     torch.manual_seed(1)
     ora = randomize_(OracleModelV2(2, 3, pretrained_backbone=False)).eval()

@@ -65,3 +65,14 @@ def test_box_utils_bit_exact(cases):
 def test_constants(cases):
     c = cases["constants"]
     assert (postprocess.CONF_TH, postprocess.NMS_IOU, postprocess.TOP_K) == (c["CONF_TH"], c["NMS_IOU"], c["TOP_K"])
+
+
+def test_weighted_add_of_oldest_variant_bit_exact(cases):
+    """src/model.py:27-36: `sum(w_i + f)` -- the weights are added, not multiplied."""
+    from oracle.model import WeightedAdd
+    for n in (2, 3):
+        c = cases[f"WeightedAdd_{n}"]
+        m = WeightedAdd(n)
+        with torch.no_grad():
+            m.w.copy_(c["w"])
+            assert torch.equal(m(c["inputs"]), c["output"])
