@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the ~220 launches of a step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
+    ap.add_argument("--ab-graph", default="", help="dev: comma list of VAR=val; each is re-lowered, re-captured and its graph replay timed")
     ap.add_argument("--ab", default="", help="dev: comma list of MTBT_CONV_POLICY values to A/B inside this process")
     args = ap.parse_args()
 
@@ -121,6 +122,29 @@ def main():
     elapsed = timed_steps(step, args.steps, lambda: torch.cuda.synchronize(dev))
     res = step()
 
+    if rank == 0 and args.ab_graph:
+        import time
+        keep_graphs = []
+        for rnd in range(2):
+            for pol in args.ab_graph.split(","):
+                for kv in pol.split("+"):
+                    var, _, val = kv.rpartition("=")
+                    os.environ[var] = val
+                model.__dict__.pop("_plans", None)
+                g = GraphedInference(model, x, IMG)
+                for _ in range(3):
+                    g.replay()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    g.replay()
+                torch.cuda.synchronize(dev)
+                print(f"graph A/B {pol} round {rnd}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
+                keep_graphs.append(g)  # destroying a captured multi-stream graph mid-process crashed the runtime once: keep them
+        for pol in args.ab_graph.split(","):
+            for kv in pol.split("+"):
+                os.environ.pop(kv.rpartition("=")[0], None)
+        model.__dict__.pop("_plans", None)
     if rank == 0 and args.ab:
         import re, collections
         def cat(n):

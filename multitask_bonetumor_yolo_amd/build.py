@@ -15,6 +15,8 @@ SOURCES = ["conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_f32.hip", "dwcon
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-fno-gpu-rdc", "-Wno-unused-value"]
+if os.environ.get("MTBT_CONV_ABLATION"):  # development build: MTBT_CONV_DEBUG ablation bits live in the conv K loop
+    FLAGS.append("-DMTBT_CONV_ABLATION")
 
 
 def _newer(target, deps):

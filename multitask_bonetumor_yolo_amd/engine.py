@@ -73,6 +73,7 @@ class Pool:
         self.free_list = {}
         self.all = []
         self.bytes = 0
+        self.reuse = True  # False: released buffers are not handed out again (no false dependencies between branches)
 
     def get(self, shape, dtype) -> torch.Tensor:
         key = (tuple(shape), dtype)
@@ -85,6 +86,8 @@ class Pool:
         return t
 
     def put(self, t: torch.Tensor):
+        if not self.reuse:
+            return
         self.free_list.setdefault((tuple(t.shape), t.dtype), []).append(t)
 
 
@@ -96,6 +99,36 @@ class Launch:
     keep: tuple = ()  # python objects that own the memory the argument block points to
     flops: float = 0.0
     bytes: float = 0.0
+    reads: tuple = ()   # memory regions (see _region) this launch reads / writes: the scheduler's dependency source
+    writes: tuple = ()
+
+
+def _region(a):
+    """Dependency-tracking key of an activation view (or a plain tensor): (storage address, channel lo, hi, row pitch).
+    A channel slice of a wider buffer (ld > C) is tracked by its channel range; everything else as the whole buffer."""
+    if isinstance(a, torch.Tensor):
+        return (a.untyped_storage().data_ptr(), 0, 1 << 30, 0)
+    key = a.buf.untyped_storage().data_ptr()
+    if a.ld != a.C:
+        c0 = a.off % a.ld
+        return (key, c0, c0 + a.C, a.ld)
+    return (key, 0, 1 << 30, 0)
+
+
+def _overlap(r, s):
+    return r[0] == s[0] and (r[3] != s[3] or r[3] == 0 or (r[1] < s[2] and s[1] < r[2]))
+
+
+def _covers(w, r):
+    """True if a write to region w overwrites every byte region r tracks (so older records of r can be dropped)."""
+    return w[0] == r[0] and (w[3] == 0 or (w[3] == r[3] and w[1] <= r[1] and r[2] <= w[2]))
+
+
+class _Schedule:
+    pass
+
+
+_LANE_STREAMS = {}
 
 
 class Plan:
@@ -107,13 +140,152 @@ class Plan:
         self.consts = []  # folded weights etc. (kept alive)
 
     # ---- execution ----
-    def run(self, stream: Optional[int] = None, start: int = 0, end: Optional[int] = None):
-        """Issue launches [start, end) on the current (or given) stream."""
-        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream)
-        for l in self.launches[start:end]:
-            rc = l.fn(*l.args, s)
+    def run(self, stream: Optional[int] = None, start: int = 0, end: Optional[int] = None, marks=None):
+        """Issue the plan.  Default: the launches are spread over `lanes()` HIP streams following their data
+        dependencies (see schedule()); lane 0 is the caller's current stream, the others fork from it at the start and
+        join it at the end, so to the caller the plan still looks like work on its current stream (and a HIP-graph
+        capture of that stream records the lanes as parallel branches).  `marks` = launch indices; returns one event per
+        lane that covers them (recorded after the last marked launch of that lane) so that a consumer stream can start
+        as soon as those launches are done.  A sub-range [start, end) or an explicit `stream` runs sequentially."""
+        sequential = stream is not None or start != 0 or (end is not None and end != len(self.launches)) or self.lanes() <= 1
+        if sequential:
+            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream)
+            last_mark, evs = (max(marks) if marks else -1), []
+            for i, l in enumerate(self.launches[start:end], start):
+                rc = l.fn(*l.args, s)
+                if rc != 0:
+                    L.check(rc, l.name)
+                if i == last_mark:
+                    evs.append(torch.cuda.Event())
+                    evs[0].record(torch.cuda.current_stream(self.device))
+            return evs
+        sch = self.schedule()
+        if sch.events is None:
+            sch.events = [torch.cuda.Event() for _ in range(sch.n_events)]
+            sch.fork_event = torch.cuda.Event()
+            sch.join_events = [torch.cuda.Event() for _ in range(sch.n_lanes - 1)]
+        main = torch.cuda.current_stream(self.device)
+        streams = [main] + self._side_streams(sch.n_lanes - 1)
+        ptrs = [C.c_void_p(st.cuda_stream) for st in streams]
+        fork = sch.fork_event
+        fork.record(main)
+        used = sch.used_side_lanes  # lanes that got no launch stay out of the fork / join (and out of a graph capture)
+        for k in used:
+            streams[k].wait_event(fork)
+        mark_last = {}
+        for i in (marks or ()):
+            ln = sch.lane[i]
+            mark_last[ln] = max(mark_last.get(ln, -1), i)
+        mark_at = {i: torch.cuda.Event() for i in mark_last.values()}
+        launches = self.launches
+        for i in sch.order:
+            ln = sch.lane[i]
+            for e in sch.waits[i]:
+                streams[ln].wait_event(sch.events[e])
+            l = launches[i]
+            rc = l.fn(*l.args, ptrs[ln])
             if rc != 0:
                 L.check(rc, l.name)
+            e = sch.records[i]
+            if e >= 0:
+                sch.events[e].record(streams[ln])
+            if i in mark_at:
+                mark_at[i].record(streams[ln])
+        for k in used:
+            sch.join_events[k - 1].record(streams[k])
+            main.wait_event(sch.join_events[k - 1])
+        return list(mark_at.values())
+
+    def lanes(self) -> int:
+        import os
+        return max(1, int(os.environ.get("MTBT_LANES", "4")))
+
+    def _side_streams(self, n):
+        # process-wide per device and never destroyed: captured graphs may outlive the plan that recorded them
+        cur = _LANE_STREAMS.setdefault(torch.device(self.device).index or 0, [])
+        while len(cur) < n:
+            cur.append(torch.cuda.Stream(device=self.device))
+        return cur[:n]
+
+    def dependencies(self):
+        """Per launch, the earlier launches it must wait for: read-after-write, write-after-write and write-after-read on
+        the regions the op builders recorded.  Buffers recycled by the pool are tracked by address, so reuse stays safe."""
+        hist = {}  # storage address -> (writers [(region, idx)], readers [(region, idx)])
+        deps = []
+        for i, l in enumerate(self.launches):
+            d = set()
+            for r in l.reads:
+                ws, _ = hist.get(r[0], ((), ()))
+                d.update(j for (wr, j) in ws if _overlap(r, wr))
+            for w in l.writes:
+                ws, rs = hist.setdefault(w[0], ([], []))
+                d.update(j for (wr, j) in ws if _overlap(w, wr))
+                d.update(j for (rr, j) in rs if _overlap(w, rr))
+            for w in l.writes:
+                ws, rs = hist[w[0]]
+                ws[:] = [(wr, j) for (wr, j) in ws if not _covers(w, wr)] + [(w, i)]
+                rs[:] = [(rr, j) for (rr, j) in rs if not _covers(w, rr)]
+            for r in l.reads:
+                hist.setdefault(r[0], ([], []))[1].append((r, i))
+            d.discard(i)
+            deps.append(sorted(d))
+        return deps
+
+    def schedule(self):
+        """List-schedule the launches onto lanes (HIP streams) in program order with a simple duration model: a launch
+        starts when its dependencies and its lane are free; it takes the lane where it can start first, preferring the
+        lane of the dependency it waits for last (a chain stays on one stream and needs no event).  Cross-lane
+        dependencies become event record / wait pairs."""
+        import os
+        n_lanes = self.lanes()
+        wide_s = float(os.environ.get("MTBT_LANE_WIDE_US", "60")) * 1e-6
+        c = self.__dict__.get("_sched")
+        if c is not None and c.n_launches == len(self.launches) and c.n_lanes == n_lanes and c.wide_s == wide_s:
+            return c
+        deps = self.dependencies()
+        n = len(self.launches)
+        lane, finish = [0] * n, [0.0] * n
+        free = [0.0] * n_lanes
+        for i, l in enumerate(self.launches):
+            dur = max(l.flops / 4e14, l.bytes / 2e12) + 6e-6
+            ready, crit = 0.0, -1
+            for j in deps[i]:
+                if finish[j] >= ready:
+                    ready, crit = finish[j], j
+            # Side lanes exchange events with lane 0 only: a side stream that waits on another side stream which itself
+            # waited on the first (a fork/join nested below a non-origin stream) segfaults hipStreamEndCapture on ROCm 7.2
+            # (tools/capture_topo.py).  So a launch may sit on lane 0, or on the one side lane its dependencies live on.
+            side = {lane[j] for j in deps[i]} - {0}
+            allowed = range(n_lanes) if not side else ([0] + list(side) if len(side) == 1 else [0])
+            best = min(allowed, key=lambda k: (max(ready, free[k]), k))
+            if crit >= 0 and lane[crit] in allowed and free[lane[crit]] <= max(ready, free[best]) + 1e-9:
+                best = lane[crit]
+            if i == 0 or dur - 6e-6 >= wide_s:
+                best = 0  # the first launch reads the caller's input; machine-filling launches stay serialized on lane 0
+            lane[i] = best
+            finish[i] = max(ready, free[best]) + dur
+            free[best] = finish[i]
+        # events: launch j records one if some launch on another lane depends on it; a lane waits for (lane', j) once
+        records, waits, n_events = [-1] * n, [[] for _ in range(n)], 0
+        waited = {}
+        for i in range(n):
+            for j in deps[i]:
+                a, b = lane[i], lane[j]
+                if a == b or waited.get((a, b), -1) >= j:
+                    continue
+                waited[(a, b)] = j
+                if records[j] < 0:
+                    records[j] = n_events
+                    n_events += 1
+                waits[i].append(records[j])
+        sch = _Schedule()
+        sch.n_launches, sch.n_lanes, sch.wide_s = n, n_lanes, wide_s
+        sch.order, sch.lane, sch.deps = list(range(n)), lane, deps
+        sch.records, sch.waits, sch.n_events, sch.events = records, waits, n_events, None  # HIP events: created by run()
+        sch.used_side_lanes = sorted(set(lane) - {0})
+        sch.est_makespan = max(finish) if n else 0.0
+        self.__dict__["_sched"] = sch
+        return sch
 
     def run_timed(self):
         """Replay with a HIP event pair around every launch (all on torch's current stream, which is the stream
@@ -167,6 +339,7 @@ class Plan:
         flops = 2.0 * x.N * Ho * Wo * K * R * S * x.C
         byts = (x.N * x.H * x.W * x.C + K * R * S * x.C) * ESIZE[x.code] + x.N * Ho * Wo * K * ESIZE[y.code]
         self.launches.append(Launch(self.lib.mtbt_conv2d_nhwc, (C.byref(a),), name, (a, x.buf, w, y.buf, scale, shift, res), flops, byts))
+        self._io([x, res], [y])
         return a
 
     def stem(self, x_nchw: torch.Tensor, w, b, lnw, lnb, eps, y: Act, name="stem"):
@@ -176,6 +349,7 @@ class Plan:
         self.launches.append(Launch(self.lib.mtbt_stem_conv4x4_ln, args, name, (x_nchw, w, b, lnw, lnb, y.buf),
                                     2.0 * N * (H // 4) * (W // 4) * y.C * 48,
                                     N * 3 * H * W * 4 + N * (H // 4) * (W // 4) * y.C * ESIZE[y.code]))
+        self._io([], [y])
 
     def dwconv(self, x: Act, w, y: Act, ksize, *, bias=None, lnw=None, lnb=None, eps=0.0, scale=None, shift=None,
                act=L.ACT_NONE, name="dwconv"):
@@ -186,6 +360,7 @@ class Plan:
         n = x.N * x.H * x.W * x.C
         self.launches.append(Launch(self.lib.mtbt_dwconv_nhwc, args, name, (x.buf, w, bias, lnw, lnb, scale, shift, y.buf),
                                     2.0 * n * ksize * ksize, 2.0 * n * ESIZE[x.code]))
+        self._io([x], [y])
 
     def layernorm(self, x: Act, w, b, eps, y: Act, name="layernorm"):
         assert x.dense and y.dense
@@ -193,6 +368,7 @@ class Plan:
         args = (x.ptr, w.data_ptr(), b.data_ptr(), C.c_float(eps), y.ptr, pixels, x.C, x.code)
         self.launches.append(Launch(self.lib.mtbt_layernorm_nhwc, args, name, (x.buf, w, b, y.buf), 0.0,
                                     2.0 * pixels * x.C * ESIZE[x.code]))
+        self._io([x], [y])
 
     def fuse(self, inputs, weights, modes, y: Act, bug=False, name="bifpn_fuse"):
         a = L.FuseArgs()
@@ -204,6 +380,7 @@ class Plan:
         n = y.N * y.H * y.W * y.C
         self.launches.append(Launch(self.lib.mtbt_bifpn_fuse, (C.byref(a),), name, (a, y.buf) + tuple(t.buf for t in inputs),
                                     0.0, n * ESIZE[y.code] * (1 + len(inputs))))
+        self._io(list(inputs), [y])
         return a
 
     def gap_fc(self, x: Act, w, b, y: torch.Tensor, name="gap_fc"):
@@ -212,6 +389,7 @@ class Plan:
                 w.shape[0], x.code)
         self.launches.append(Launch(self.lib.mtbt_gap_fc, args, name, (x.buf, w, b, y), 0.0,
                                     x.N * x.H * x.W * x.C * ESIZE[x.code]))
+        self._io([x], [y])
 
     def bn_train(self, x: Act, y: Act, bn, act, name="bn_train"):
         """BatchNorm with batch statistics + activation over a dense NHWC tensor; updates bn.running_* in place."""
@@ -228,12 +406,21 @@ class Plan:
                 x.code, ws.data_ptr(), nbytes)
         self.launches.append(Launch(self.lib.mtbt_bn_train_nhwc, args, name, (x.buf, y.buf, g, b, ws, bn), 0.0,
                                     3.0 * pixels * x.C * ESIZE[x.code]))
+        self._io([x], [y])
 
     def cast(self, x: Act, y: Act, name="cast"):
         assert x.dense and y.dense
         n = x.N * x.H * x.W * x.C
         self.launches.append(Launch(self.lib.mtbt_cast, (x.ptr, y.ptr, n, x.code, y.code), name, (x.buf, y.buf), 0.0,
                                     n * (ESIZE[x.code] + ESIZE[y.code])))
+        self._io([x], [y])
 
-    def raw(self, fn, args, name, keep=()):
+    def raw(self, fn, args, name, keep=(), reads=(), writes=()):
         self.launches.append(Launch(fn, args, name, keep))
+        self._io(list(reads), list(writes))
+
+    def _io(self, reads, writes):
+        """Record what the launch just appended reads and writes (activation views or tensors; None entries are skipped)."""
+        l = self.launches[-1]
+        l.reads = tuple(_region(a) for a in reads if a is not None)
+        l.writes = tuple(_region(a) for a in writes if a is not None)

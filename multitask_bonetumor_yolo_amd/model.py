@@ -11,6 +11,7 @@ weights version) into a launch plan (engine.Plan) of C-ABI calls and replays it.
 There is no CPU path: tensors must live on an MI355X and the HIP library must be built.
 """
 import math
+import os
 from typing import List
 
 import torch
@@ -568,13 +569,17 @@ class _Base(nn.Module):
                 c3, c4, c5 = lo.backbone()
                 n3, n4, n5 = lo.neck(c3, c4, c5)
             feats = [n3, n4, n5]
+            # the head branches (3 levels x detect / segment / cv4 + Proto) are independent: no buffer recycling between
+            # them, so the lane scheduler (engine.Plan.schedule) sees no false write-after-read dependencies
+            lo.p.pool.reuse = os.environ.get("MTBT_HEAD_REUSE", "0") == "1"
             det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
-            det_done = len(lo.p.launches)  # launches [0, det_done) produce the Detect maps: post-process can fork here
             seg_maps = lo.det_branch(feats, self.segment, "segment")
             mc, protos = lo.seg_extras(feats, self.segment)
             logits = lo.cls_head(n5)
         c = _Compiled(lo.p, xs, det_maps, seg_maps, mc, protos, logits, sig)
-        c.det_done = det_done if det_maps is not None else len(lo.p.launches)
+        # launches that write the maps the box decode reads: the post-process forks as soon as these are done
+        keys = {m.buf.untyped_storage().data_ptr() for m in (det_maps if det_maps is not None else seg_maps)}
+        c.det_marks = [i for i, l in enumerate(lo.p.launches) if any(w[0] in keys for w in l.writes)]
         c.train_bns = lo.train_bns
         cache[key] = c
         return c
@@ -607,12 +612,12 @@ class _Base(nn.Module):
             maps = c.det_maps if c.det_maps is not None else c.seg_maps
             main = torch.cuda.current_stream(x.device)
             side = side_stream or self.__dict__.setdefault("_side_stream", torch.cuda.Stream(device=x.device))
-            c.plan.run(end=c.det_done)
-            side.wait_stream(main)
+            ready = c.plan.run(marks=c.det_marks)
             with torch.cuda.stream(side):
+                for ev in ready:
+                    side.wait_event(ev)
                 d = pp.decode_boxes([m.nchw() for m in maps], img_size, want_scores=False)
                 k = pp.nms_batched(d["boxes"], d["best_score"], d["best_label"], float(img_size), conf_th, iou_th, top_k)
-            c.plan.run(start=c.det_done)
             main.wait_stream(side)
             out = {"boxes": k["boxes"], "scores": k["scores"], "labels": k["labels"], "counts": k["counts"],
                    "keep_idx": k["keep_idx"], "keep_anchor": k["keep_anchor"], "n_cand": k["n_cand"]}

@@ -127,3 +127,39 @@ def test_gloo_world_size_2_timing_contract(tmp_path):
     rows = sorted(line.split() for o in outs for line in o.splitlines() if line.startswith("RANK"))
     assert (rows[0][1], rows[0][2], rows[1][1], rows[1][2]) == ("0", "17", "17", "33")
     assert rows[0][3] == rows[1][3] and float(rows[0][3]) >= 0.06  # MAX over ranks: the slow rank's 3 x 20 ms
+
+
+def test_plan_dependencies_and_lanes(monkeypatch):
+    """engine.Plan: data dependencies from the recorded read / write regions (incl. channel slices of a concat buffer and
+    pool-recycled buffers) and the lane assignment of independent branches.  No launch is executed (CPU tensors)."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    from multitask_bonetumor_yolo_amd.engine import Plan
+    monkeypatch.setenv("MTBT_LANES", "3")
+    p = Plan(torch.device("cpu"))
+    w = torch.zeros(64, 64, dtype=torch.bfloat16)
+    a = p.new(1, 8, 8, 64, L.BF16)
+    cat = p.new(1, 8, 8, 128, L.BF16)
+    p.conv(a, w, cat.slice(0, 64), name="l0")           # 0: a -> cat[0:64]
+    p.conv(a, w, cat.slice(64, 64), name="l1")          # 1: a -> cat[64:128]   (independent of 0: disjoint slices)
+    b = p.new(1, 8, 8, 64, L.BF16)
+    p.conv(cat.slice(0, 64), w, b, name="l2")           # 2: reads slice 0 -> depends on 0 only
+    c = p.new(1, 8, 8, 64, L.BF16)
+    p.conv(cat.slice(64, 64), w, c, name="l3")          # 3: reads slice 1 -> depends on 1 only
+    d = p.new(1, 8, 8, 64, L.BF16)
+    p.fuse([b, c], [0.5, 0.5], [L.RES_ID, L.RES_ID], d, name="l4")   # 4: joins 2 and 3
+    p.release(b)
+    e = p.new(1, 8, 8, 64, L.BF16)                      # recycles b's storage
+    assert e.buf is b.buf
+    p.conv(a, w, e, name="l5")                          # 5: write-after-read on b (read by 4) and write-after-write (2)
+    p.conv(cat, w[:, :64].repeat(1, 2).contiguous(), c, name="l6")   # 6: whole cat (0, 1) ; overwrites c (read by 4, written by 3)
+    deps = p.dependencies()
+    assert deps == [[], [], [0], [1], [2, 3], [2, 4], [0, 1, 3, 4]]
+    s = p.schedule()
+    assert s.lane[0] != s.lane[1]                       # the two independent convs run on different lanes
+    assert s.lane[2] == s.lane[0] and s.lane[3] == s.lane[1]   # chains stay on their lane
+    for i in range(len(deps)):                          # every cross-lane dependency is covered by an event wait
+        for j in deps[i]:
+            if s.lane[j] != s.lane[i]:
+                covered = any(s.records[k] in s.waits[m] for k in range(j, i) if s.lane[k] == s.lane[j] and s.records[k] >= 0
+                              for m in range(k + 1, i + 1) if s.lane[m] == s.lane[i])
+                assert covered, (i, j)

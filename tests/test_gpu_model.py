@@ -239,3 +239,23 @@ def test_errors(pair):
         hip(torch.rand(1, 3, 65, 64, device=DEV), "infer")
     with pytest.raises(RuntimeError):
         hip(torch.rand(1, 3, 64, 64), "infer")  # CPU tensor: no CPU path
+
+
+def test_lane_schedule_matches_sequential(monkeypatch):
+    """engine.Plan.run over 4 HIP streams (dependency-driven lanes) gives bit-identical results to one stream."""
+    torch.manual_seed(3)
+    from multitask_bonetumor_yolo_amd import init_synthetic_
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.rand(2, 3, 128, 128, device=DEV)
+    outs = []
+    for lanes in ("1", "4", "6"):
+        monkeypatch.setenv("MTBT_LANES", lanes)
+        hip.__dict__.pop("_plans", None)
+        for _ in range(3):  # repeated runs: lanes of run k+1 must not overtake readers of run k
+            fwd, det = hip.infer_and_detect(x, 128)
+        torch.cuda.synchronize()
+        outs.append((fwd["segment_preds_cat"].clone(), fwd["detect_preds_cat"].clone(), fwd["img_cls_logits"].clone(),
+                     fwd["segment_protos"][2].clone(), det["keep_idx"].clone(), det["masks"].clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)

@@ -19,6 +19,10 @@ SHAPES = {
     "c2f_p5.m 3x3 256->256 @20": (16, 20, 20, 256, 256, 3, 1, False),
     "bifpn.m 3x3 128->128 @40": (16, 40, 40, 128, 128, 3, 1, False),
     "head 3x3 256->64 @80": (16, 80, 80, 256, 64, 3, 1, False),
+    "bifpn.m 3x3 128->128 @20": (16, 20, 20, 128, 128, 3, 1, False),
+    "head 3x3 256->64 @20": (16, 20, 20, 256, 64, 3, 1, False),
+    "head 3x3 64->64 @20": (16, 20, 20, 64, 64, 3, 1, False),
+    "bifpn pw 1x1 256->256 @20": (16, 20, 20, 256, 256, 1, 2, False),
     "fc1.s0 1x1 96->384 @160": (16, 160, 160, 96, 384, 1, 3, False),
     "fc2.s0 1x1 384->96 @160": (16, 160, 160, 384, 96, 1, 0, True),
     "fc1.s1 1x1 192->768 @80": (16, 80, 80, 192, 768, 1, 3, False),
