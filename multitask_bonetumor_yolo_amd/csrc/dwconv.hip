@@ -14,21 +14,33 @@
 //   * all chunks' accumulators stay in registers; the LayerNorm statistics (ConvNeXt conv_dw + norm)
 //     are per-thread partial sums + one LDS transpose-reduce per wave (a wave holds ALL channels of its
 //     16 pixels), two-pass mean/variance, then the normalised pairs are stored straight from registers.
+#include <cstdlib>
+
 #include "common.h"
+#include "conv_dma.h"
+
+int mtbt_dw_chunked(const void* x, const void* w, const float* bias, const float* lnw, const float* lnb, float eps,
+                    const float* scale, const float* shift, int act, void* y, int N, int H, int W, int C, int ksize, int dtype,
+                    hipStream_t s);  // dwconv_chunked.hip
 
 namespace {
 
+// A channel pair as a 2-vector: `fma2` on it is ONE v_pk_fma_f32 (left as separate .x/.y fmaf calls the SLP
+// vectoriser pairs values across pixels instead and pays ~0.6 shuffle moves per packed FMA).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <typename T> struct Pair;
 template <> struct Pair<float> {
-  static __device__ __forceinline__ float2 ld(const void* p) { return *reinterpret_cast<const float2*>(p); }
-  static __device__ __forceinline__ void st(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+  static __device__ __forceinline__ f32x2 ld(const void* p) { return *reinterpret_cast<const f32x2*>(p); }
+  static __device__ __forceinline__ void st(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
 };
 template <> struct Pair<bf16_t> {
-  static __device__ __forceinline__ float2 ld(const void* p) {
+  static __device__ __forceinline__ f32x2 ld(const void* p) {
     const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
-    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+    return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
   }
-  static __device__ __forceinline__ void st(bf16_t* p, float2 v) {
+  static __device__ __forceinline__ void st(bf16_t* p, f32x2 v) {
     *reinterpret_cast<uint32_t*>(p) = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
   }
 };
@@ -60,162 +72,248 @@ __device__ __forceinline__ void wave_sum16(float (&v)[16], float* red, int lane)
 
 constexpr int CC = 128;  // channels per chunk = 64 lanes x 2
 
-// MAXCH = ceil(C / 128) chunks held in registers.
-template <typename T, int KS, bool LN, int TH, int TW, int MAXCH>
-__global__ __launch_bounds__((TH / 2) * (TW / 8) * 64, 2) void dwconv_kernel(
+static int dbg_env() { const char* d = getenv("MTBT_DW_DEBUG"); return d ? atoi(d) : 0; }  // development ablation bits
+
+// MAXCH = ceil(C / 128) chunks held in registers.  Workgroups are PERSISTENT: each walks a strided list of tiles
+// (XCD-contiguous ranges, so neighbouring tiles' halos meet in one L2); with a single chunk (C <= 128) the taps stay
+// in registers across tiles.
+template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB>
+__global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
     const T* __restrict__ x, const T* __restrict__ w /* [KS*KS][C] */, const float* __restrict__ bias,
     const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, const float* __restrict__ scale,
-    const float* __restrict__ shift, int act, T* __restrict__ y, int N, int H, int W, int C) {
-  constexpr int PAD = KS / 2, XB = 8, YB = 2, SPAN = XB + KS - 1, ROWS = YB + KS - 1;
+    const float* __restrict__ shift, int act, T* __restrict__ y, int N, int H, int W, int C, int dbg) {
+  constexpr int PAD = KS / 2, YB = 2, SPAN = XB + KS - 1, ROWS = YB + KS - 1;
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
   constexpr int ES = (int)sizeof(T), PIXB = CC * ES;  // bytes per staged pixel
-  constexpr int NT = (TH / 2) * (TW / 8) * 64;
+  constexpr int NW = (TH / 2) * (TW / XB);            // waves
+  // staging geometry: one LDS-DMA wave-instruction = 1 KiB = PXI whole pixels of ONE halo row
+  constexpr int PARTS = PIXB / 16, PXI = 64 / PARTS, IWP = ((IW + PXI - 1) / PXI) * PXI, SEGS = IWP / PXI;
+  constexpr int NDMA = IH * SEGS, DPW = (NDMA + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tile = smem;                         // [IH*IW][CC] T
-  char* wl = smem + IH * IW * PIXB;          // [KS*KS][CC] T
+  char* tile = smem;                                  // [IH][IWP][CC] T
+  constexpr int TILEB = IH * IWP * PIXB;
+  // LayerNorm scratch: its own region when C <= 128 (the next tile's DMA is already landing in `tile` during the
+  // epilogue); with several chunks it reuses the tile (LDS would otherwise not fit two workgroups per CU)
+  constexpr int REDOFF = MAXCH == 1 ? TILEB : 0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const int bt = blockIdx.x;
-  const int tx = bt % tiles_x, ty = (bt / tiles_x) % tiles_y, n = bt / (tiles_x * tiles_y);
-  const int ty0 = ty * TH, tx0 = tx * TW;
-  const int sy = wave / (TW / 8), sx = wave % (TW / 8);  // sub-tile of this wave
+  const int total = N * tiles_y * tiles_x;
+  const int sy = wave / (TW / XB), sx = wave % (TW / XB);  // sub-tile of this wave
   const int nchunks = (C + CC - 1) / CC;
-  const T* xn = x + (long)n * H * W * C;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned rowbytes = (unsigned)(W * C * ES);
+  const unsigned vlane = (unsigned)((lane / PARTS) * C * ES + (lane % PARTS) * 16);  // lane's piece inside a DMA segment
 
-  float2 acc[MAXCH][YB][XB];
-#pragma unroll
-  for (int k = 0; k < MAXCH; ++k)
-#pragma unroll
-    for (int a = 0; a < YB; ++a)
-#pragma unroll
-      for (int i = 0; i < XB; ++i) acc[k][a][i] = make_float2(0.f, 0.f);
+  // tile walk: workgroups b, b+8, ... share an XCD; each XCD owns a contiguous range of tiles
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (total + 7) >> 3, step = gridDim.x >> 3;
+  const int t_end = min(total, (xcd + 1) * per_xcd);
 
+  // Taps (fp32 pairs of this lane's channel pair).  One chunk (C <= 128): all KS*KS stay in registers across the tiles.
+  // More chunks: registers are needed for the accumulators of every chunk, so the taps are fetched row by row (KS at a
+  // time, straight from L2) inside the unrolled row loop -- only two filter rows are live at once.
+  constexpr bool REGTAPS = MAXCH == 1;  // all KS*KS taps in registers
+  f32x2 wr[REGTAPS ? KS * KS : 1];
+  if (MAXCH == 1 && lane * 2 < C) {
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) wr[REGTAPS ? t : 0] = Pair<T>::ld(w + (unsigned)(t * C + lane * 2));
+  }
+
+  // per-channel epilogue vectors of this lane's channel pairs: loaded once (a load inside the epilogue would expose a
+  // full memory round trip per tile)
+  f32x2 e0[MAXCH], e1[MAXCH], e2[MAXCH];  // LN: bias, ln weight, ln bias ; else: scale, shift, -
 #pragma unroll
   for (int k = 0; k < MAXCH; ++k) {
-    if (k >= nchunks) break;
-    const int cb = k * CC;                       // chunk base channel
-    const int cc = min(CC, C - cb);              // channels in this chunk (multiple of 8)
-    const int parts = cc * ES / 16;              // 16-byte pieces per pixel
-    if (k > 0) __syncthreads();                  // previous chunk's readers are done
-    for (int pc = tid; pc < IH * IW * parts; pc += NT) {
-      const int pix = pc / parts, part = pc - pix * parts;
-      const int r = pix / IW, c = pix - r * IW;
-      const int iy = ty0 + r - PAD, ix = tx0 + c - PAD;
-      uint4 v = uint4{0u, 0u, 0u, 0u};
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xn + ((long)iy * W + ix) * C + cb) + part * 16);
-      *reinterpret_cast<uint4*>(tile + pix * PIXB + part * 16) = v;
-    }
-    for (int pc = tid; pc < KS * KS * parts; pc += NT) {
-      const int t = pc / parts, part = pc - t * parts;
-      *reinterpret_cast<uint4*>(wl + t * PIXB + part * 16) =
-          *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w + (long)t * C + cb) + part * 16);
-    }
-    __syncthreads();
-    if (lane * 2 < cc) {
-      const char* lp = tile + lane * 2 * ES;
-      const char* wp = wl + lane * 2 * ES;
-      // rows stay a rolled loop: taps come from LDS (runtime index is free), and a fully unrolled body lets the
-      // scheduler hoist every LDS read and blow the register budget
-#pragma unroll 1
-      for (int r = 0; r < ROWS; ++r) {
-        float2 in[SPAN];
-#pragma unroll
-        for (int j = 0; j < SPAN; ++j) in[j] = Pair<T>::ld(lp + ((sy * YB + r) * IW + sx * XB + j) * PIXB);
-#pragma unroll
-        for (int a = 0; a < YB; ++a) {
-          const int ky = r - a;
-          if (ky >= 0 && ky < KS) {
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-              const float2 wv = Pair<T>::ld(wp + (ky * KS + kx) * PIXB);
-#pragma unroll
-              for (int i = 0; i < XB; ++i) {
-                acc[k][a][i].x = fmaf(in[i + kx].x, wv.x, acc[k][a][i].x);
-                acc[k][a][i].y = fmaf(in[i + kx].y, wv.y, acc[k][a][i].y);
-              }
-            }
-          }
-        }
+    const int c0 = k * CC + lane * 2;
+    e0[k] = e1[k] = e2[k] = f32x2{0.f, 0.f};
+    if (c0 < C) {
+      if constexpr (LN) {
+        e0[k] = *reinterpret_cast<const f32x2*>(bias + c0);
+        e1[k] = *reinterpret_cast<const f32x2*>(lnw + c0);
+        e2[k] = *reinterpret_cast<const f32x2*>(lnb + c0);
+      } else {
+        e0[k] = *reinterpret_cast<const f32x2*>(scale + c0);
+        e1[k] = *reinterpret_cast<const f32x2*>(shift + c0);
       }
     }
   }
 
-  const int oy0 = ty0 + sy * YB, ox0 = tx0 + sx * XB;
-  if constexpr (LN) {
-    // + bias, per-pixel statistics over all C channels (held by this wave), normalise, store
-    __syncthreads();  // every wave is done with the staged tile: its LDS is reused for the reductions
-    float* red = reinterpret_cast<float*>(smem) + wave * (16 * 64 + 16);
-    float s[YB * XB];
+  // Halo tile global -> LDS by LDS-DMA (conv_dma.h), addresses on the SCALAR
+  // unit: one buffer descriptor per halo row (base = that image row, num_records = its bytes); rows above / below the
+  // image use an empty descriptor and columns outside it an out-of-range offset: both land as zeros.  Per instruction
+  // the vector unit only adds one scalar to the lane's constant piece offset and tests its column.  Every wave issues its
+  // DPW pieces back to back; the caller waits once (s_waitcnt vmcnt(0) + barrier).
+  auto stage = [&](int tl_, int cb) {
+    const int tx_ = tl_ % tiles_x, ty_ = (tl_ / tiles_x) % tiles_y, n_ = tl_ / (tiles_x * tiles_y);
+    const char* xn = reinterpret_cast<const char*>(x + (long)n_ * H * W * C);
 #pragma unroll
-    for (int pq = 0; pq < YB * XB; ++pq) s[pq] = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      const int c0 = k * CC + lane * 2;
-      if (k < nchunks && c0 < C) {
-        const float2 bv = *reinterpret_cast<const float2*>(bias + c0);
-#pragma unroll
-        for (int a = 0; a < YB; ++a)
-#pragma unroll
-          for (int i = 0; i < XB; ++i) {
-            acc[k][a][i].x += bv.x; acc[k][a][i].y += bv.y;
-            s[a * XB + i] += acc[k][a][i].x + acc[k][a][i].y;
-          }
-      }
+    for (int d = 0; d < DPW; ++d) {
+      const int j = d * NW + wave_u;
+      if (NDMA % NW != 0 && j >= NDMA) break;
+      const int row = j / SEGS, seg = j - row * SEGS;
+      const int iy = ty_ * TH + row - PAD;
+      const bool rowok = (unsigned)iy < (unsigned)H;
+      srd_t srd = make_srd(xn + (long)(rowok ? iy : 0) * rowbytes);
+      srd.z = __builtin_amdgcn_readfirstlane(rowok ? rowbytes : 0u);
+      srd.w = __builtin_amdgcn_readfirstlane(srd.w);
+      const int ix0 = tx_ * TW - PAD + seg * PXI;                // first pixel of this segment (may be < 0)
+      const unsigned vo = (unsigned)(ix0 + lane / PARTS) < (unsigned)W ? vlane + (unsigned)((ix0 * C + cb) * ES) : 0x80000000u;
+      if (!(dbg & 2)) lds_dma16(srd, vo, 0, __builtin_amdgcn_readfirstlane(lds0 + (row * IWP + seg * PXI) * PIXB));
     }
-    wave_sum16(s, red, lane);
-    const float invC = 1.0f / C;
-    float q[YB * XB];
+  };
+  bool first = true;
+
+  for (int tl = xcd * per_xcd + slot; tl < t_end; tl += step) {
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int ty0 = ty * TH, tx0 = tx * TW;
+
+    f32x2 acc[MAXCH][YB][XB];
 #pragma unroll
-    for (int pq = 0; pq < YB * XB; ++pq) { s[pq] *= invC; q[pq] = 0.f; }
+    for (int k = 0; k < MAXCH; ++k)
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      if (k < nchunks && k * CC + lane * 2 < C) {
+      for (int a = 0; a < YB; ++a)
 #pragma unroll
-        for (int a = 0; a < YB; ++a)
-#pragma unroll
-          for (int i = 0; i < XB; ++i) {
-            const float dx = acc[k][a][i].x - s[a * XB + i], dy = acc[k][a][i].y - s[a * XB + i];
-            q[a * XB + i] += dx * dx + dy * dy;
-          }
+        for (int i = 0; i < XB; ++i) acc[k][a][i] = f32x2{0.f, 0.f};
+
+    auto chunk = [&](int k) {
+      const int cb = k * CC;                       // chunk base channel
+      const int cc = min(CC, C - cb);              // channels in this chunk (multiple of 8)
+      const bool active = lane * 2 < cc;
+      if (MAXCH > 1 || first) {                    // (one chunk: every later tile was requested during the previous epilogue)
+        __syncthreads();                           // the previous tile's / chunk's readers (and LN scratch users) are done
+        stage(tl, cb);
       }
+      wait_vm<0>();
+      __syncthreads();
+      if (active && !(dbg & 1)) {
+        const char* lp = tile + ((sy * YB) * IWP + sx * XB) * PIXB + lane * 2 * ES;
+        const T* wb = w + cb;
+        const unsigned lane2 = (unsigned)lane * 2;
+        // Fully unrolled (tap registers need compile-time indices) and software-pipelined by hand: row r+1's inputs (LDS)
+        // and, with several chunks, filter row r+1's taps (L2) are requested before row r's FMAs; a scheduling barrier
+        // per row keeps the compiler from hoisting ALL rows' loads to the top (which spills).  One input row (SPAN
+        // pairs) feeds YB output rows.
+        f32x2 wrow[3][KS], in[2][SPAN];
+        auto taps = [&](int ky) {
+          // scalar base + one shared lane offset.  The empty asm makes the row's base opaque HERE: otherwise the addresses
+          // of all 49 x chunks taps are loop-invariant, get hoisted out of the tile loop and spill.
+          const T* rb = wb + ky * KS * C;
+          asm volatile("" : "+s"(rb));
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) wrow[ky % 3][kx] = Pair<T>::ld(rb + kx * C + lane2);
+        };
+        auto inputs = [&](int r) {
+#pragma unroll
+          for (int j = 0; j < SPAN; ++j) in[r & 1][j] = Pair<T>::ld(lp + (r * IWP + j) * PIXB);
+        };
+        if (!REGTAPS) taps(0);
+        inputs(0);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          if (!REGTAPS && r + 1 < KS) taps(r + 1);
+          if (r + 1 < ROWS) inputs(r + 1);
+#pragma unroll
+          for (int a = 0; a < YB; ++a) {
+            const int ky = r - a;
+            if (ky >= 0 && ky < KS) {
+#pragma unroll
+              for (int kx = 0; kx < KS; ++kx) {
+                const f32x2 wv = REGTAPS ? wr[REGTAPS ? ky * KS + kx : 0] : wrow[ky % 3][kx];
+#pragma unroll
+                for (int i = 0; i < XB; ++i) acc[k][a][i] = fma2(in[r & 1][i + kx], wv, acc[k][a][i]);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+#pragma clang loop unroll(full)
+    for (int k = 0; k < MAXCH; ++k)
+      if (k < nchunks) chunk(k);     // (uniform; a `break` would keep the loop rolled and acc[k] in scratch)
+    first = false;
+    const int oy0 = ty0 + sy * YB, ox0 = tx0 + sx * XB;
+    T* yt = y + (((long)n * H + oy0) * W + ox0) * C;     // wave-uniform base; per-lane offsets below stay 32-bit
+    const unsigned rowel = (unsigned)(W * C);
+    if (dbg & 4) { if (acc[0][0][0].x == 123.f) y[0] = T(0); if (MAXCH == 1) { __syncthreads(); if (tl + step < t_end) stage(tl + step, 0); } continue; }
+    if (MAXCH == 1) {   // one chunk: request the next tile now, it lands while this tile's epilogue runs
+      __syncthreads();  // every wave is done reading the staged tile
+      if (tl + step < t_end) stage(tl + step, 0);
     }
-    wave_sum16(q, red, lane);
+    if constexpr (LN) {
+      // + bias, per-pixel statistics over all C channels (held by this wave), normalise, store
+      if (MAXCH > 1) __syncthreads();  // every wave is done with the staged tile: its LDS is reused for the reductions
+      float* red = reinterpret_cast<float*>(smem + REDOFF) + wave * (16 * 64 + 16);
+      float s[16];  // wave_sum16 reduces 16 values; sub-tiles with fewer pixels leave the rest zero
 #pragma unroll
-    for (int pq = 0; pq < YB * XB; ++pq) q[pq] = rsqrtf(q[pq] * invC + eps);
+      for (int pq = 0; pq < 16; ++pq) s[pq] = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      const int c0 = k * CC + lane * 2;
-      if (k < nchunks && c0 < C) {
-        const float2 gw = *reinterpret_cast<const float2*>(lnw + c0), gb = *reinterpret_cast<const float2*>(lnb + c0);
+      for (int k = 0; k < MAXCH; ++k) {
+        const int c0 = k * CC + lane * 2;
+        if (k < nchunks && c0 < C) {
+          const f32x2 bv = e0[k];
 #pragma unroll
-        for (int a = 0; a < YB; ++a) {
-          if (oy0 + a >= H) continue;
+          for (int a = 0; a < YB; ++a)
 #pragma unroll
-          for (int i = 0; i < XB; ++i) {
-            if (ox0 + i >= W) continue;
-            const float m = s[a * XB + i], rs = q[a * XB + i];
-            Pair<T>::st(y + (((long)n * H + oy0 + a) * W + ox0 + i) * C + c0,
-                        make_float2((acc[k][a][i].x - m) * rs * gw.x + gb.x, (acc[k][a][i].y - m) * rs * gw.y + gb.y));
+            for (int i = 0; i < XB; ++i) {
+              acc[k][a][i] += bv;
+              s[a * XB + i] += acc[k][a][i].x + acc[k][a][i].y;
+            }
+        }
+      }
+      wave_sum16(s, red, lane);
+      const float invC = 1.0f / C;
+      float q[16];
+#pragma unroll
+      for (int pq = 0; pq < 16; ++pq) { s[pq] *= invC; q[pq] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < MAXCH; ++k) {
+        if (k < nchunks && k * CC + lane * 2 < C) {
+#pragma unroll
+          for (int a = 0; a < YB; ++a)
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+              const f32x2 d = acc[k][a][i] - s[a * XB + i];
+              acc[k][a][i] = d;                       // keep the centred value: the normalisation below reuses it
+              q[a * XB + i] += d.x * d.x + d.y * d.y;
+            }
+        }
+      }
+      wave_sum16(q, red, lane);
+#pragma unroll
+      for (int pq = 0; pq < YB * XB; ++pq) q[pq] = rsqrtf(q[pq] * invC + eps);
+#pragma unroll
+      for (int k = 0; k < MAXCH; ++k) {
+        const int c0 = k * CC + lane * 2;
+        if (k < nchunks && c0 < C) {
+          const f32x2 gw = e1[k], gb = e2[k];
+#pragma unroll
+          for (int a = 0; a < YB; ++a) {
+            if (oy0 + a >= H) continue;
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+              if (ox0 + i >= W) continue;
+              Pair<T>::st(yt + (a * rowel + (unsigned)(i * C + c0)), fma2(acc[k][a][i] * q[a * XB + i], gw, gb));
+            }
           }
         }
       }
-    }
-  } else {
+    } else {
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      const int c0 = k * CC + lane * 2;
-      if (k < nchunks && c0 < C) {
-        const float2 sc = *reinterpret_cast<const float2*>(scale + c0), sh = *reinterpret_cast<const float2*>(shift + c0);
+      for (int k = 0; k < MAXCH; ++k) {
+        const int c0 = k * CC + lane * 2;
+        if (k < nchunks && c0 < C) {
+          const f32x2 sc = e0[k], sh = e1[k];
 #pragma unroll
-        for (int a = 0; a < YB; ++a) {
-          if (oy0 + a >= H) continue;
+          for (int a = 0; a < YB; ++a) {
+            if (oy0 + a >= H) continue;
 #pragma unroll
-          for (int i = 0; i < XB; ++i) {
-            if (ox0 + i >= W) continue;
-            Pair<T>::st(y + (((long)n * H + oy0 + a) * W + ox0 + i) * C + c0,
-                        make_float2(act_apply(acc[k][a][i].x * sc.x + sh.x, act), act_apply(acc[k][a][i].y * sc.y + sh.y, act)));
+            for (int i = 0; i < XB; ++i) {
+              if (ox0 + i >= W) continue;
+              const f32x2 v = fma2(acc[k][a][i], sc, sh);
+              Pair<T>::st(yt + (a * rowel + (unsigned)(i * C + c0)), f32x2{act_apply(v.x, act), act_apply(v.y, act)});
+            }
           }
         }
       }
@@ -223,15 +321,22 @@ __global__ __launch_bounds__((TH / 2) * (TW / 8) * 64, 2) void dwconv_kernel(
   }
 }
 
-template <typename T, int KS, bool LN, int TH, int TW, int MAXCH>
+template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB = 8>
 int launch_dw(const void* x, const void* w, const float* bias, const float* lnw, const float* lnb, float eps,
               const float* scale, const float* shift, int act, void* y, int N, int H, int W, int C, hipStream_t s) {
-  constexpr int NT = (TH / 2) * (TW / 8) * 64;
-  constexpr int lds = ((TH + KS - 1) * (TW + KS - 1) + KS * KS) * CC * (int)sizeof(T);
+  constexpr int NT = (TH / 2) * (TW / XB) * 64;
+  constexpr int PARTS = CC * (int)sizeof(T) / 16, PXI = 64 / PARTS, IWP = ((TW + KS - 1 + PXI - 1) / PXI) * PXI;
+  constexpr int lds_tile = (TH + KS - 1) * IWP * CC * (int)sizeof(T), lds_red = LN ? (NT / 64) * (16 * 64 + 16) * 4 : 0;
+  constexpr int lds_taps = 0;
+  constexpr int lds = MAXCH == 1 ? lds_tile + lds_red : (lds_tile + lds_taps > lds_red ? lds_tile + lds_taps : lds_red);
   static_assert(lds <= 160 * 1024, "LDS");
-  const long blocks = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
-  auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH>;
+  const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  if (tiles > 0x7fffffffL) return MTBT_EINVAL;
+  // persistent workgroups: as many as stay resident (LDS-limited, at most 4 per CU), a multiple of the 8 XCDs
+  const long resident = 256L * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);
+  long blocks = tiles < resident ? tiles : resident;
+  blocks = (blocks + 7) / 8 * 8;
+  auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH, XB>;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     attr_set = true;
@@ -239,7 +344,7 @@ int launch_dw(const void* x, const void* w, const float* bias, const float* lnw,
       return MTBT_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, (const T*)x, (const T*)w, bias, lnw, lnb, eps, scale, shift,
-                     act, (T*)y, N, H, W, C);
+                     act, (T*)y, N, H, W, C, dbg_env());
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -247,11 +352,9 @@ int launch_dw(const void* x, const void* w, const float* bias, const float* lnw,
 template <typename T, int KS, bool LN, int TH, int TW>
 int dispatch_chunks(const void* x, const void* w, const float* bias, const float* lnw, const float* lnb, float eps,
                     const float* scale, const float* shift, int act, void* y, int N, int H, int W, int C, hipStream_t s) {
-  const int nch = (C + CC - 1) / CC;
+  const int nch = (C + CC - 1) / CC;  // two and three chunks go to dwconv_chunked.hip
   if (nch <= 1) return launch_dw<T, KS, LN, TH, TW, 1>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
-  if (nch <= 2) return launch_dw<T, KS, LN, TH, TW, 2>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
-  if (nch <= 3) return launch_dw<T, KS, LN, TH, TW, 3>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
-  if (nch <= 6) return launch_dw<T, KS, LN, TH, TW, 6>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
+  if (nch <= 6) return launch_dw<T, KS, LN, TH, TW / 2, 6, 4>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
   return MTBT_EINVAL;
 }
 
@@ -267,7 +370,10 @@ extern "C" int mtbt_dwconv_nhwc(const void* x, const void* w, const float* bias,
   if (ln && (!ln_b || !bias)) return MTBT_EINVAL;
   if (!ln && (!scale || !shift)) return MTBT_EINVAL;
   if (!aligned16(x) || !aligned16(y) || !aligned16(w)) return MTBT_EALIGN;
+  if ((long)(W + 64) * C * 4 >= 0x7fff0000L || (long)H * W * C >= 0x7fff0000L) return MTBT_EINVAL;  // 32-bit offsets in a row / an image
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (C > 128 && C <= 384 && (long)H * W * C * 4 < 0x7fff0000L && !(dbg_env() & 32))
+    return mtbt_dw_chunked(x, w, bias, ln_w, ln_b, ln_eps, scale, shift, act, y, N, H, W, C, ksize, dtype, s);
 #define DW_ARGS x, w, bias, ln_w, ln_b, ln_eps, scale, shift, act, y, N, H, W, C, s
   if (dtype == MTBT_BF16) {
     if (ksize == 7) return ln ? dispatch_chunks<bf16_t, 7, true, 4, 16>(DW_ARGS) : dispatch_chunks<bf16_t, 7, false, 4, 16>(DW_ARGS);
