@@ -214,6 +214,12 @@ typedef struct mtbt_mask_args {
 
 int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream);
 
+/* Pairwise IoU of xyxy boxes (running_main_v3.py:71-97, `batch_bbox_iou`): out[i][j] = inter / (area1_i + area2_j - inter + eps),
+ * inter = clamp(min(x2)-max(x1), 0) * clamp(min(y2)-max(y1), 0); fp32, the reference's operation order without FMA
+ * contraction (bit-exact with the torch CPU result).  boxes1 [n,4], boxes2 [m,4], out [n,m] row-major; n or m == 0 is a
+ * no-op (the reference returns an empty/zero matrix). */
+int mtbt_bbox_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, float eps, float* out, void* stream);
+
 /* dtype / layout helpers on the boundary */
 int mtbt_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 

@@ -19,6 +19,11 @@ if os.environ.get("MTBT_CONV_ABLATION"):  # development build: MTBT_CONV_DEBUG a
     FLAGS.append("-DMTBT_CONV_ABLATION")
 
 
+# per-file flags: the post-process must round like the CPU reference (separate multiply / add; hipcc's default
+# -ffp-contract=fast fuses them in the backend even across `#pragma clang fp contract(off)`)
+EXTRA_FLAGS = {"postprocess.hip": ["-ffp-contract=off"]}
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -33,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         if force or _newer(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -3,6 +3,10 @@
 // no FMA contraction, IEEE division, stable ordering.
 #include "common.h"
 
+// No FMA contraction in this file (built with -ffp-contract=off, see build.py): the NMS suppression test and the
+// pairwise IoU must round exactly like the CPU reference (torchvision / torch eager evaluate every product and sum
+// separately).  hipcc's default contracts in the backend, and the __fmul_rn / __fadd_rn spellings are plain operators.
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -368,7 +372,41 @@ inline long nms_ws_per_image(int A) {
   return (b + 255) / 256 * 256;
 }
 
+// pairwise IoU: thread = (row i, 4 consecutive columns j); boxes2 is small (ground-truth boxes) and stays in L1/L2
+__global__ void bbox_iou_kernel(const float4* __restrict__ b1, int n, const float4* __restrict__ b2, int m, float eps,
+                                float* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int mg = (m + 3) >> 2;
+  const long i = t / mg;
+  const int j0 = (int)(t - i * mg) * 4;
+  if (i >= n) return;
+  const float4 a = b1[i];
+  const float a1 = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+  for (int j = j0; j < j0 + 4 && j < m; ++j) {
+    const float4 b = b2[j];
+    const float a2 = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+    const float iw = fmaxf(__fsub_rn(fminf(a.z, b.z), fmaxf(a.x, b.x)), 0.f);
+    const float ih = fmaxf(__fsub_rn(fminf(a.w, b.w), fmaxf(a.y, b.y)), 0.f);
+    const float inter = __fmul_rn(iw, ih);
+    out[i * m + j] = __fdiv_rn(inter, __fadd_rn(__fsub_rn(__fadd_rn(a1, a2), inter), eps));
+  }
+}
+
 }  // namespace
+
+extern "C" int mtbt_bbox_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, float eps, float* out, void* stream) {
+  if (n < 0 || m < 0) return MTBT_EINVAL;
+  if (n == 0 || m == 0) return MTBT_OK;
+  if (!boxes1 || !boxes2 || !out) return MTBT_EINVAL;
+  if (!aligned16(boxes1) || !aligned16(boxes2)) return MTBT_EALIGN;
+  const long total = (long)n * ((m + 3) / 4);
+  const long blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  hipLaunchKernelGGL(bbox_iou_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(boxes1), n, reinterpret_cast<const float4*>(boxes2), m, eps, out);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
 
 extern "C" int mtbt_decode_boxes(const mtbt_decode_args* a, void* stream) {
   if (!a || a->n_levels < 1 || a->n_levels > 3 || a->N <= 0 || a->nc <= 0 || a->reg_max <= 0 || a->reg_max > 64) return MTBT_EINVAL;

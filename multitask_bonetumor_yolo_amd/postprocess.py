@@ -88,6 +88,19 @@ def detect_inference(maps, head, mc: Optional[torch.Tensor] = None) -> torch.Ten
     return cat.permute(0, 2, 1)
 
 
+def batch_bbox_iou(boxes1: torch.Tensor, boxes2: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """running_main_v3.py:71-97: pairwise IoU [N,M] of xyxy boxes; an empty side gives the reference's zero matrix."""
+    lib = L.load()
+    _need_cuda(boxes1, "batch_bbox_iou")
+    n, m = boxes1.shape[0], boxes2.shape[0]
+    out = torch.zeros((n, m), dtype=torch.float32, device=boxes1.device)
+    if n and m:
+        b1, b2 = boxes1.contiguous().float(), boxes2.to(boxes1.device).contiguous().float()
+        L.check(lib.mtbt_bbox_iou_pairwise(b1.data_ptr(), n, b2.data_ptr(), m, C.c_float(eps), out.data_ptr(), _stream(boxes1.device)),
+                "mtbt_bbox_iou_pairwise")
+    return out
+
+
 def nms_batched(boxes: torch.Tensor, best_score: torch.Tensor, best_label: Optional[torch.Tensor], clamp_max: float,
                 conf_th: float = CONF_TH, iou_th: float = NMS_IOU, top_k: int = TOP_K):
     """running_main_v3.py:535-552 for the whole batch: score > conf_th, clamp to [0, clamp_max], greedy NMS

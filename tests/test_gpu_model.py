@@ -259,3 +259,26 @@ def test_lane_schedule_matches_sequential(monkeypatch):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+def test_high_resolution_1280_pipeline():
+    """BASELINE config 4 shape (1280x1280, 33600 anchors per image; the large-A NMS path): the fused step equals the two
+    plain calls bit for bit, and the oracle's filter + NMS on the GPU-decoded boxes keeps the same indices."""
+    from multitask_bonetumor_yolo_amd import init_synthetic_
+    torch.manual_seed(11)
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    S = 1280
+    x = torch.rand(1, 3, S, S, device=DEV)
+    fwd, det = hip.infer_and_detect(x, S)
+    with torch.no_grad():
+        out = hip(x, "infer")
+    feats, mc, protos = out["segment_protos"]
+    assert out["detect_preds_cat"].shape == (1, 4 + 2, 33600) and protos.shape == (1, 32, S // 4, S // 4)
+    res = pp.detect_and_segment(out["detect_features"], mc, protos, S)
+    torch.cuda.synchronize()
+    assert torch.equal(det["keep_idx"], res["keep_idx"]) and torch.equal(det["masks"], res["masks"])
+    d = pp.decode_boxes(out["detect_features"], S)
+    k, anchors, kb, ks, kl = opp.filter_and_nms(d["boxes"][0].cpu(), d["scores"][0].cpu(), S)
+    n = int(res["counts"][0])
+    assert n == len(k) and n > 0
+    assert torch.equal(res["keep_idx"][0, :n].cpu(), k) and torch.equal(res["boxes"][0, :n].cpu(), kb)

@@ -143,3 +143,21 @@ def test_mask_assembly_and_projector(hp, wp):
         torch.cuda.synchronize()
         ref = opp.proto_projector_logits(protos, w, bias, SH)
         assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 1e-3
+
+
+def test_batch_bbox_iou_bit_exact():
+    """pairwise IoU against the reference's own vectors (tests/golden) and the oracle, bit for bit."""
+    import os
+    cases = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_blocks.pt"), weights_only=True)
+    b1, b2 = cases["batch_bbox_iou"]["inputs"]
+    got = pp.batch_bbox_iou(b1.to(DEV), b2.to(DEV))
+    assert torch.equal(got.cpu(), cases["batch_bbox_iou"]["output"])
+    e1, e2 = cases["batch_bbox_iou_empty"]["inputs"]
+    assert torch.equal(pp.batch_bbox_iou(e1.to(DEV), e2.to(DEV)).cpu(), cases["batch_bbox_iou_empty"]["output"])
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(8400, 2, generator=g) * 600
+    a = torch.cat([xy, xy + torch.rand(8400, 2, generator=g) * 120], 1)
+    xy2 = torch.rand(7, 2, generator=g) * 600
+    b = torch.cat([xy2, xy2 + torch.rand(7, 2, generator=g) * 200], 1)
+    b[3] = a[17]  # identical box: IoU ~ 1
+    assert torch.equal(pp.batch_bbox_iou(a.to(DEV), b.to(DEV)).cpu(), opp.batch_bbox_iou(a, b))
