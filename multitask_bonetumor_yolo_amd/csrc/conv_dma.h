@@ -35,6 +35,16 @@ __device__ __forceinline__ void lds_dma16(srd_t srd, unsigned voffset, int soffs
       : "memory");
 }
 
+// Workgroup barrier of the LDS-DMA pipelines.  Two things the bare `__builtin_amdgcn_s_barrier()` does not give:
+//  * `s_waitcnt lgkmcnt(0)` first: the buffer restaged right after this barrier is the one this wave read LAST step;
+//    the compiler may leave those ds_reads in flight across the barrier (it parks the MFMAs that consume them behind
+//    it), and a pending read that loses the race against another wave's DMA write returns the NEW bytes (WAR);
+//  * a compiler memory barrier: the builtin is IntrNoMem, so fragment reads of the NEXT step may be hoisted above it,
+//    i.e. before the other waves' DMA pieces have landed (RAW).
+// Both showed up as rare wrong tiles only when the CU was shared with another kernel (LDS port contention stretches
+// the window); found with tools/pair_stress.py.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until at most k*G vector-memory operations (LDS-DMA pieces) of this wave are outstanding, k in [0, KMAX]
 template <int G, int KMAX> __device__ __forceinline__ void wait_stages(int k) {

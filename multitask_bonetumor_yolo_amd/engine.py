@@ -73,11 +73,12 @@ class Pool:
         self.free_list = {}
         self.all = []
         self.bytes = 0
-        self.reuse = True  # False: released buffers are not handed out again (no false dependencies between branches)
+        import os
+        self.reuse = os.environ.get("MTBT_POOL_REUSE", "1") == "1"  # False: released buffers are never handed out again
 
     def get(self, shape, dtype) -> torch.Tensor:
         key = (tuple(shape), dtype)
-        lst = self.free_list.get(key)
+        lst = self.free_list.get(key) if self.reuse else None
         if lst:
             return lst.pop()
         t = torch.empty(shape, dtype=dtype, device=self.device)
@@ -178,12 +179,20 @@ class Plan:
             mark_last[ln] = max(mark_last.get(ln, -1), i)
         mark_at = {i: torch.cuda.Event() for i in mark_last.values()}
         launches = self.launches
+        import os
+        serial = os.environ.get("MTBT_LANE_SERIAL") == "1"  # dev: total order across lanes (no two launches overlap)
+        prev_ev, prev_ln = None, -1
         for i in sch.order:
             ln = sch.lane[i]
             for e in sch.waits[i]:
                 streams[ln].wait_event(sch.events[e])
+            if serial and prev_ev is not None and prev_ln != ln:
+                streams[ln].wait_event(prev_ev)
             l = launches[i]
             rc = l.fn(*l.args, ptrs[ln])
+            if serial:
+                prev_ev, prev_ln = torch.cuda.Event(), ln
+                prev_ev.record(streams[ln])
             if rc != 0:
                 L.check(rc, l.name)
             e = sch.records[i]
@@ -244,6 +253,7 @@ class Plan:
             return c
         deps = self.dependencies()
         n = len(self.launches)
+        win = [int(v) for v in os.environ.get("MTBT_LANE_WINDOW", "0:1000000").split(":")]  # dev: side lanes only in [a, b)
         lane, finish = [0] * n, [0.0] * n
         free = [0.0] * n_lanes
         for i, l in enumerate(self.launches):
@@ -260,7 +270,7 @@ class Plan:
             best = min(allowed, key=lambda k: (max(ready, free[k]), k))
             if crit >= 0 and lane[crit] in allowed and free[lane[crit]] <= max(ready, free[best]) + 1e-9:
                 best = lane[crit]
-            if i == 0 or dur - 6e-6 >= wide_s:
+            if i == 0 or dur - 6e-6 >= wide_s or not (win[0] <= i < win[1]):
                 best = 0  # the first launch reads the caller's input; machine-filling launches stay serialized on lane 0
             lane[i] = best
             finish[i] = max(ready, free[best]) + dur

@@ -571,7 +571,7 @@ class _Base(nn.Module):
             feats = [n3, n4, n5]
             # the head branches (3 levels x detect / segment / cv4 + Proto) are independent: no buffer recycling between
             # them, so the lane scheduler (engine.Plan.schedule) sees no false write-after-read dependencies
-            lo.p.pool.reuse = os.environ.get("MTBT_HEAD_REUSE", "0") == "1"
+            lo.p.pool.reuse = lo.p.pool.reuse and os.environ.get("MTBT_HEAD_REUSE", "0") == "1"
             det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
             seg_maps = lo.det_branch(feats, self.segment, "segment")
             mc, protos = lo.seg_extras(feats, self.segment)

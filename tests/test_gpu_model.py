@@ -282,3 +282,32 @@ def test_high_resolution_1280_pipeline():
     n = int(res["counts"][0])
     assert n == len(k) and n > 0
     assert torch.equal(res["keep_idx"][0, :n].cpu(), k) and torch.equal(res["boxes"][0, :n].cpu(), kb)
+
+
+def test_concurrent_lanes_are_deterministic_at_full_size(monkeypatch):
+    """Batch 16 x 640^2 on four lanes, eager and graph replay, 40 steps each: bit-identical to the single-stream result.
+    (Guards the LDS-DMA pipelines' barrier discipline: a missing lgkmcnt(0) before the restaging barrier produced rare wrong
+    tiles only when a CU was shared with another kernel.)"""
+    from multitask_bonetumor_yolo_amd import init_synthetic_
+    from multitask_bonetumor_yolo_amd.graphed import GraphedInference
+    torch.manual_seed(5)
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.rand(16, 3, 640, 640, device=DEV)
+
+    def snap(fwd, det):
+        return [t.clone() for t in (fwd["segment_preds_cat"], fwd["detect_preds_cat"], fwd["segment_protos"][2],
+                                    fwd["img_cls_logits"], det["keep_idx"], det["masks"])]
+    monkeypatch.setenv("MTBT_LANES", "1")
+    ref = snap(*hip.infer_and_detect(x, 640))
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MTBT_LANES", "4")
+    hip.__dict__.pop("_plans", None)
+    for _ in range(40):
+        got = snap(*hip.infer_and_detect(x, 640))
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    g = GraphedInference(hip, x, 640)
+    for _ in range(40):
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, snap(g.fwd, g.out)))
