@@ -191,10 +191,20 @@ def main():
                 print(f"{t*1e3:9.1f} us  {tf:7.1f} TF/s  {l.bytes/(t*1e-3)/1e9 if t>0 else 0:8.0f} GB/s  {l.name}", file=sys.stderr)
             print(f"plan: {len(c.plan.launches)} launches, {all_ms:.3f} ms (conv {conv_ms:.3f} ms, {len(conv)} launches), "
                   f"pool {c.plan.pool.bytes/2**20:.0f} MiB", file=sys.stderr)
+        # HBM-side traffic of the same kernels: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command, summarised
+        # by tools/summarize_pmc.py with the guide's gfx950 corrections; bench.py cannot run the profiler on itself
+        traffic, traffic_src = None, None
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            if name.endswith("_traffic.json") and args.dtype == "bf16":
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic, traffic_src = round(json.load(f)["traffic_bytes_per_launch"]), "profiles/" + name
+                break
+        conv_bytes = sum(l.bytes for l, _ in conv)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_direct_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv_bytes / len(conv)),
                     "launches_per_step": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
                     "flop_per_launch": round(conv_flops / len(conv)), "conv_ms_per_step": round(conv_ms, 3),
                     "all_kernels_ms_per_step": round(all_ms, 3)}

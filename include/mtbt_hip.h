@@ -38,6 +38,8 @@ extern "C" {
 #define MTBT_ACT_SILU 1 /* main_model.py:136 ; ultralytics Conv */
 #define MTBT_ACT_ELU 2  /* main_model.py:96 */
 #define MTBT_ACT_GELU 3 /* timm Mlp act (erf form), main_model.py:21-26 [upstream] */
+#define MTBT_ACT_GELU_POLY 4 /* the same GELU as x * Phi(x) with Phi an odd degree-13 polynomial on [-4,4]: |error| <= 2.3e-4,
+                              below bf16 resolution; no exp / rcp.  For bf16 outputs (the fp32 parity mode uses MTBT_ACT_GELU). */
 
 /* conv output addressing */
 #define MTBT_OUT_NHWC 0
@@ -213,6 +215,13 @@ typedef struct mtbt_mask_args {
 } mtbt_mask_args;
 
 int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream);
+
+/* Fused ConvNeXt MLP (timm Mlp fc1 -> GELU -> fc2 with the layer-scale folded, + residual) for d in {96, 192}, bf16 only:
+ *   y[p][:] = res[p][:] + W2' . GELU(W1 . t[p][:] + b1) + b2'      (the 4d-wide hidden tensor never leaves the chip)
+ * t, res, y: dense [M][d] bf16; w1 [4d][d] bf16; b1 [4d] f32; b2 [d] f32; w2p [d][4d] bf16 whose columns are reordered
+ * inside every group of 32 hidden units: slot 8g+j holds hidden 4g+j (j < 4) or 16+4g+(j-4) (j >= 4), g = 0..3. */
+int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
+                            const float* b2, void* y, int64_t M, int D, void* stream);
 
 /* Pairwise IoU of xyxy boxes (running_main_v3.py:71-97, `batch_bbox_iou`): out[i][j] = inter / (area1_i + area2_j - inter + eps),
  * inter = clamp(min(x2)-max(x1), 0) * clamp(min(y2)-max(y1), 0); fp32, the reference's operation order without FMA

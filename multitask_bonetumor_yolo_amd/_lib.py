@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_CONVT2X2 = 0, 1
 RES_ID, RES_UP_BILINEAR, RES_DOWN_MEAN, RES_UP_NEAREST, RES_MAXPOOL = 0, 1, 2, 3, 4
 
@@ -74,6 +74,7 @@ SYMBOLS = {
     "mtbt_nms_batched": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
                          + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
     "mtbt_mask_assemble": (C.c_int, [C.POINTER(MaskArgs), C.c_void_p]),
+    "mtbt_convnext_mlp_fused": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mtbt_bbox_iou_pairwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -71,11 +71,27 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 
+// GELU(x) = x * Phi(x), Phi(x) - 1/2 = xc * P(xc^2) with xc = clamp(x, -4, 4): weighted least-squares fit on Chebyshev
+// nodes (max |GELU error| 2.3e-4 over all x, relative 3.6e-5 for x > 4).  11 plain VALU operations, no transcendental:
+// the erf form costs 2 half-rate + ~14 plain and made the GELU, not the MFMAs, the bound of the fused ConvNeXt MLP.
+__device__ __forceinline__ float gelu_poly(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  const float s = xc * xc;
+  float p = fmaf(2.1609857e-08f, s, -1.5335673e-06f);
+  p = fmaf(p, s, 4.6542096e-05f);
+  p = fmaf(p, s, -7.9887325e-04f);
+  p = fmaf(p, s, 8.6900834e-03f);
+  p = fmaf(p, s, -6.4366050e-02f);
+  p = fmaf(p, s, 3.9770728e-01f);
+  return x * fmaf(xc, p, 0.5f);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case MTBT_ACT_SILU: return v * fast_rcp(1.0f + fast_exp(-v));
     case MTBT_ACT_ELU: return v > 0.0f ? v : (v > -0.03f ? expm1f(v) : fast_exp(v) - 1.0f);
     case MTBT_ACT_GELU: return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    case MTBT_ACT_GELU_POLY: return gelu_poly(v);
     default: return v;
   }
 }

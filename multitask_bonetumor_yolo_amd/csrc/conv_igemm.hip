@@ -71,7 +71,7 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   if (a->Ho != (a->H + 2 * a->pad - a->R) / a->stride + 1 || a->Wo != (a->W + 2 * a->pad - a->S) / a->stride + 1) return MTBT_EINVAL;
   if (a->out_mode != MTBT_OUT_NHWC && a->out_mode != MTBT_OUT_CONVT2X2) return MTBT_EINVAL;
   if (a->out_mode == MTBT_OUT_CONVT2X2 && (a->K % 4 != 0)) return MTBT_EINVAL;
-  if (a->act < 0 || a->act > MTBT_ACT_GELU) return MTBT_EINVAL;
+  if (a->act < 0 || a->act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
   if (!aligned16(a->x) || !aligned16(a->w) || a->x_pixel_stride % epc != 0 || a->x_batch_stride % epc != 0) return MTBT_EALIGN;
   if (a->x_pixel_stride < a->C) return MTBT_EINVAL;
 

@@ -1,0 +1,258 @@
+// Fused ConvNeXt MLP for the wide-map stages (d = 96, 192), bf16:
+//
+//     y[p][:] = res[p][:] + W2' . GELU(W1 . t[p][:] + b1) + b2'          (timm Mlp fc1 -> GELU -> fc2, layer-scale folded)
+//
+// Unfused, the 4d-wide hidden tensor makes two HBM round trips (16 x 160^2 x 384 bf16 = 315 MB in stage 0) and both
+// 1x1 convs sit on the HBM roof (77 FLOP/B).  Here a workgroup keeps its pixels' hidden activations ON CHIP:
+//
+//   * a wave owns FP x 16 pixels; their fc1 inputs t[p][0..d) live in REGISTERS for the whole kernel as MFMA B fragments
+//     (loaded straight from global: a lane's 16-byte piece of a pixel row IS its fragment);
+//   * the hidden dimension is walked in chunks of 32: GEMM1 (rows = 32 hidden units of W1, k = d) gives, per lane, 4 + 4
+//     consecutive hidden units of one pixel -- after bias + GELU + bf16 rounding these 8 values ARE the B fragment of
+//     GEMM2 (k = 32 hidden units) if fc2's weight columns are stored in the matching order (packed once on the host:
+//     slot 8g+j <- hidden 4g+j for j < 4, 16+4g+(j-4) otherwise).  No LDS round trip, no transposition;
+//   * GEMM2 (rows = d output channels) accumulates y in registers over all chunks;
+//   * only the weights stream: per chunk W1_j [32][d] and W2'_j [d][32] go global -> LDS by LDS-DMA (three LDS stages,
+//     counted vmcnt, conv_dma.h) as 64-byte-row slabs with the conv kernel's swizzle; per wave and chunk that is
+//     6-12 ds_read_b128 for 48 MFMAs;
+//   * the residual initialises the output accumulators; epilogue = + b2', bf16, 8-byte stores from the accumulators.
+//
+// HBM traffic per pixel: read t, read res, write y (3 x 2d bytes) instead of 2d + 8d + 8d + 2d + 2d.
+#include <cstdlib>
+
+#include "common.h"
+#include "conv_params.h"
+#include "conv_dma.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+// two floats -> packed bf16 pair, one v_cvt_pk_bf16_f32 (round to nearest even)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+// 64-byte-row swizzle of conv_igemm.inc (CPR = 4)
+__device__ __forceinline__ int swz4(int row) { return (-(row >> 2)) & 3; }
+
+struct MlpP {
+  const bf16_t* t;     // [M][D] fc1 input (LayerNorm output)
+  const bf16_t* w1;    // [4D][D]
+  const float* b1;     // [4D]
+  const bf16_t* w2p;   // [D][4D], hidden order permuted per 32-chunk (see top)
+  const bf16_t* res;   // [M][D] residual (may be NULL)
+  int M;
+  int dbg;             // development ablation bits (MTBT_MLP_DEBUG): 1 = no GELU, 2 = no GEMM2, 4 = no GEMM1, 8 = no weight DMA
+  ConvP ep;            // epilogue view: shift = b2', res, y, K = D
+};
+
+template <int D, int FP>
+__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpP p) {
+  constexpr int KS1 = D / 32;            // k-steps of GEMM1
+  constexpr int FC = D / 16;             // output-channel fragments of GEMM2
+  constexpr int NCH = 4 * D / 32;        // hidden chunks
+  constexpr int PW = FP * 16, P = 4 * PW;  // pixels per wave / workgroup
+  constexpr int W1B = 32 * D * 2, W2B = D * 64;  // bytes of one chunk's weight tiles
+  constexpr int STAGE = W1B + W2B;
+  constexpr int NDMA = STAGE / 1024, DPW = NDMA / 4;  // LDS-DMA instructions per stage, per wave
+  static_assert(NDMA % 4 == 0 && W1B % 1024 == 0, "whole wave-instructions");
+  constexpr int NBUF = 3;                // LDS stages: two chunks' weights in flight behind the one being multiplied
+  static_assert(NCH % NBUF == 0, "chunk loop is unrolled by the stage count");
+  constexpr int AFF_OFF = NBUF * STAGE;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* aff = reinterpret_cast<float*>(smem + AFF_OFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int pbase = blockIdx.x * P + wave * PW;
+  stage_affine<D>(p.ep, aff, 0, tid);
+  // fc1 bias: LDS copy (a compiler-managed global load inside the chunk loop would make hipcc wait vmcnt(0) at its use and
+  // drain the weight prefetch that is in flight)
+  float* b1s = aff + 2 * D;
+  for (int c = tid; c < 4 * D; c += 256) b1s[c] = p.b1[c];
+
+  // ---- weight staging: constant per-lane source offsets, scalar chunk offsets ----
+  // stage layout: W1_j as KS1 slabs [32 rows][64 B], then W2'_j as [D rows][64 B]; piece c of a slab -> row c/4,
+  // slot c%4 fed with source chunk (c%4) ^ swz4(row) (swizzle on the source side, LDS image lane-linear).
+  const srd_t w1srd = make_srd(p.w1), w2srd = make_srd(p.w2p);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned voff[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int inst = i * 4 + wave;                       // wave-instruction index inside the stage (scalar)
+    const int c = inst * 64 + lane;                      // 16-byte piece index inside the stage
+    if (inst * 1024 < W1B) {                             // (W1B is a multiple of 1 KiB: an instruction never straddles)
+      const int slab = c / 128, r = (c % 128) / 4, q = (c % 4) ^ swz4(r);
+      voff[i] = (unsigned)(r * D * 2 + slab * 64 + q * 16);          // + chunk * 32 rows * D * 2 (scalar)
+    } else {
+      const int c2 = c - W1B / 16;
+      const int r = c2 / 4, q = (c2 % 4) ^ swz4(r);
+      voff[i] = (unsigned)(r * 4 * D * 2 + q * 16);                  // + chunk * 64 (scalar)
+    }
+  }
+  auto stage = [&](int j, int buf) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int inst = i * 4 + wave;
+      const unsigned dst = lds0 + buf * STAGE + inst * 1024;
+      if (inst * 1024 < W1B) lds_dma16(w1srd, voff[i], j * 32 * D * 2, dst);
+      else lds_dma16(w2srd, voff[i], j * 64, dst);
+    }
+  };
+
+  // ---- this wave's fc1 inputs as B fragments, straight from global (zeros past M) ----
+  uint4 tf[FP][KS1];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const int pix = pbase + f * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      tf[f][ks] = (pix < p.M && !(p.dbg & 64)) ? *reinterpret_cast<const uint4*>(p.t + (long)pix * D + ks * 32 + lq * 8) : uint4{0u, 0u, 0u, 0u};
+  }
+
+  // The output accumulators START as the residual: a lane's 4 channels of a pixel are 8 contiguous bytes of the residual
+  // row, requested here (their latency hides under the whole chunk loop) -- the epilogue then has no global load in its
+  // LDS-slab chain (with one it was 80 of the kernel's 166 us at d = 96: four dependent load round trips per workgroup).
+  f32x4 acc2[FC][FP];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const int pix = pbase + f * 16 + lr;
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+      uint2 r = uint2{0u, 0u};
+      if (p.res && pix < p.M) r = *reinterpret_cast<const uint2*>(p.res + (long)pix * D + i * 16 + lq * 4);
+      acc2[i][f] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                         __uint_as_float(r.y & 0xffff0000u)};
+    }
+  }
+
+  // fragment read offsets inside a stage
+  int a1off[KS1], a2off;
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) a1off[ks] = ks * 2048 + lr * 64 + ((lq ^ swz4(lr)) << 4);   // + blk * 16 rows * 64
+  a2off = W1B + lr * 64 + ((lq ^ swz4(lr)) << 4);                                              // + i * 16 rows * 64
+
+  stage(0, 0);
+  stage(1, 1);
+#pragma unroll 1
+  for (int j = 0; j < NCH; j += NBUF) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {  // unrolled by the LDS stages: buffer offsets are immediates
+      const int jj = j + u;
+      // this wave's pieces of chunk jj have landed (the next chunk's may still be in flight; the tf loads are older)
+      if (jj + 1 < NCH) wait_vm<DPW>(); else wait_vm<0>();
+      lds_barrier();                  // everyone's have, and everyone is done reading the buffer restaged next
+      if (jj + 2 < NCH && !(p.dbg & 8)) stage(jj + 2, (u + 2) % NBUF);
+      const char* st = smem + u * STAGE;
+      // bias of this chunk's 32 hidden units: rows 4 lq .. +3 of block a and of block b
+      const float4 ba = *reinterpret_cast<const float4*>(b1s + jj * 32 + lq * 4);
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + jj * 32 + 16 + lq * 4);
+      // GEMM1: hidden[32][PW] = W1_j . t
+      f32x4 h[2][FP];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) h[b][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!(p.dbg & 4))
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const uint4 wa = *reinterpret_cast<const uint4*>(st + a1off[ks]);
+        const uint4 wb = *reinterpret_cast<const uint4*>(st + a1off[ks] + 1024);
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+          h[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tf[f][ks]), h[0][f], 0, 0, 0);
+          h[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, tf[f][ks]), h[1][f], 0, 0, 0);
+        }
+      }
+      // bias + GELU + bf16: the lane's 4 + 4 hidden units of pixel lr are GEMM2's B fragment (see top)
+      uint4 hb[FP];
+#pragma unroll
+      for (int f = 0; f < FP; ++f) {
+#define G_(v) ((p.dbg & 1) ? (v) : gelu_poly(v))
+        const float a0 = G_(h[0][f][0] + ba.x), a1 = G_(h[0][f][1] + ba.y);
+        const float a2 = G_(h[0][f][2] + ba.z), a3 = G_(h[0][f][3] + ba.w);
+        const float c0 = G_(h[1][f][0] + bb.x), c1 = G_(h[1][f][1] + bb.y);
+        const float c2 = G_(h[1][f][2] + bb.z), c3 = G_(h[1][f][3] + bb.w);
+#undef G_
+        hb[f].x = pk_bf16(a0, a1); hb[f].y = pk_bf16(a2, a3);
+        hb[f].z = pk_bf16(c0, c1); hb[f].w = pk_bf16(c2, c3);
+      }
+      // GEMM2: y[D][PW] += W2'_j . hidden
+      if (!(p.dbg & 2))
+#pragma unroll
+      for (int i = 0; i < FC; ++i) {
+        const uint4 w2 = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
+#pragma unroll
+        for (int f = 0; f < FP; ++f)
+          acc2[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), __builtin_bit_cast(bf16x8, hb[f]), acc2[i][f], 0, 0, 0);
+      }
+    }
+  }
+  // Epilogue: + b2' and 8-byte bf16x4 stores STRAIGHT from the accumulators (a lane owns 4 consecutive channels of a
+  // pixel; the four lq groups of a pixel write 32 contiguous bytes, the wave's FC passes complete the 2d-byte row).
+  // Measured against the conv kernels' LDS-slab epilogue (16-byte stores after a transposition through LDS): 23 us
+  // instead of 57 us of the kernel's time at d = 96 -- the slab's serialized LDS round trips cost more than the wider
+  // stores save.
+  if (p.dbg & 32) { if (acc2[0][0][0] == 123.f) reinterpret_cast<bf16_t*>(p.ep.y)[0] = 0; return; }
+  bf16_t* yb = reinterpret_cast<bf16_t*>(p.ep.y);
+#pragma unroll
+  for (int i = 0; i < FC; ++i) {
+    const float4 sh = *reinterpret_cast<const float4*>(aff + D + i * 16 + lq * 4);
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const int pix = pbase + f * 16 + lr;
+      if (pix >= p.M) continue;
+      uint2 o;
+      o.x = pk_bf16(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
+      o.y = pk_bf16(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
+      *reinterpret_cast<uint2*>(yb + (long)pix * D + i * 16 + lq * 4) = o;
+    }
+  }
+}
+
+template <int D, int FP>
+int launch_mlp(const MlpP& p, hipStream_t s) {
+  constexpr int P = 4 * FP * 16;
+  constexpr int STAGE = 32 * D * 2 + D * 64;
+  constexpr int lds = 3 * STAGE + 2 * D * 4 + 4 * D * 4;
+  static_assert(lds <= 160 * 1024, "LDS");
+  const long blocks = ((long)p.M + P - 1) / P;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    attr_set = true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<D, FP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MTBT_ELAUNCH;
+  }
+  hipLaunchKernelGGL((mlp_fused_kernel<D, FP>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+}  // namespace
+
+// t, res, y: dense [M][D] bf16 (y may not alias t; it may alias res only if equal pixel-for-pixel, which the in-place
+// residual stream does not need).  w1 [4D][D] bf16, b1 [4D] f32, w2p [D][4D] bf16 with the per-32 hidden permutation,
+// b2 [D] f32.  D in {96, 192}.
+extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
+                                       const float* b2, void* y, int64_t M, int D, void* stream) {
+  if (!t || !w1 || !b1 || !w2p || !b2 || !y || M <= 0 || M > 0x7fffff00L) return MTBT_EINVAL;
+  if (D != 96 && D != 192) return MTBT_EINVAL;
+  if (!aligned16(t) || !aligned16(w1) || !aligned16(w2p) || !aligned16(y) || !aligned16(b1) || (res && !aligned16(res))) return MTBT_EALIGN;
+  if ((long)4 * D * D * 2 >= 0x7fff0000L) return MTBT_EINVAL;
+  MlpP p;
+  p.t = reinterpret_cast<const bf16_t*>(t); p.w1 = reinterpret_cast<const bf16_t*>(w1); p.b1 = b1;
+  p.w2p = reinterpret_cast<const bf16_t*>(w2p); p.M = (int)M;
+  { const char* d = getenv("MTBT_MLP_DEBUG"); p.dbg = d ? atoi(d) : 0; }
+  ConvP& e = p.ep;
+  e = ConvP{};
+  p.res = (p.dbg & 16) ? nullptr : reinterpret_cast<const bf16_t*>(res);
+  e.y = y; e.res = nullptr;   // the residual enters through the accumulators, not the epilogue
+  e.scale = nullptr; e.shift = b2; e.K = D; e.ldy = D; e.ldr = D; e.act = MTBT_ACT_NONE;
+  e.out_mode = MTBT_OUT_NHWC; e.out_f32 = 0; e.vec_ok = 1; e.M = (int)M;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return D == 96 ? launch_mlp<96, 4>(p, s) : launch_mlp<192, 2>(p, s);
+}

@@ -32,7 +32,8 @@ class GraphedInference:
 
     def _step(self):
         img_size, conf_th, iou_th, top_k, masks = self.args
-        return self.model.infer_and_detect(self.x, img_size, conf_th, iou_th, top_k, masks, side_stream=self.side)
+        return self.model.infer_and_detect(self.x, img_size, conf_th, iou_th, top_k, masks, side_stream=self.side,
+                                           own_outputs=False)   # static outputs: a replay overwrites them anyway
 
     def replay(self):
         self.graph.replay()

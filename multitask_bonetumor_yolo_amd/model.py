@@ -207,6 +207,16 @@ def _bn_fold(bn: nn.BatchNorm2d, conv_bias=None):
     return scale, shift
 
 
+def _permute_hidden(w2: torch.Tensor) -> torch.Tensor:
+    """fc2 weight [d][4d] -> column order of mlp_fused.hip: inside every group of 32 hidden units, slot 8g+j holds hidden
+    4g+j (j < 4) or 16+4g+(j-4) (j >= 4): a lane's GEMM1 accumulators (4 + 4 hidden units) are then GEMM2's fragment."""
+    kk = torch.arange(32)
+    g, j = kk // 8, kk % 8
+    within = torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4))
+    idx = (torch.arange(w2.shape[1] // 32)[:, None] * 32 + within[None, :]).reshape(-1)
+    return w2[:, idx.to(w2.device)].contiguous()
+
+
 def _krsc(w: torch.Tensor) -> torch.Tensor:
     """[K,C,R,S] -> [K, R*S*C]."""
     return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
@@ -363,7 +373,8 @@ class _Lowering:
             sb = self.subbatch(si, a)
             out_full = self.p.new(a.N, a.H, a.W, d, self.code)
             t = self.p.new(sb, a.H, a.W, d, self.code)
-            h = self.p.new(sb, a.H, a.W, 4 * d, self.code)
+            fused = self.code == L.BF16 and d in (96, 192) and sb == a.N and os.environ.get("MTBT_FUSED_MLP", "1") == "1"
+            h = None if fused else self.p.new(sb, a.H, a.W, 4 * d, self.code)
             pp_ = [self.p.new(sb, a.H, a.W, d, self.code) for _ in range(2)] if len(st.blocks) > 1 else []
             consts = []
             for blk in st.blocks:
@@ -371,6 +382,9 @@ class _Lowering:
                 consts.append((self.W(blk.conv_dw.weight.detach().reshape(d, 49).t()), self.F(blk.conv_dw.bias), self.F(blk.norm.weight),
                                self.F(blk.norm.bias), self.W(blk.mlp.fc1.weight), self.F(blk.mlp.fc1.bias),
                                self.W(blk.mlp.fc2.weight.detach().float() * g[:, None]), self.F(g * blk.mlp.fc2.bias.detach().float())))
+            w2p = [self.p.const(_permute_hidden(c_[6]), self.dt) for c_ in consts] if fused else None
+            # bf16 mode: polynomial GELU (|err| <= 2.3e-4, below bf16 resolution); fp32 parity mode: the erf form
+            gelu = L.ACT_GELU_POLY if self.code == L.BF16 and os.environ.get("MTBT_GELU_POLY", "1") == "1" else L.ACT_GELU
             for n0 in range(0, a.N, sb):
                 nn_ = min(sb, a.N - n0)
                 view = lambda act, k=nn_, o=n0: Act(act.buf, act.off + o * act.bs, k, act.H, act.W, act.C, act.ld, act.bs)
@@ -380,11 +394,14 @@ class _Lowering:
                     bn_ = f"{nm}.blocks.{bi}" + (f"[{n0}:{n0 + nn_}]" if sb < a.N else "")
                     dww, dwb, lnw, lnb, w1, b1, w2, b2 = consts[bi]
                     self.p.dwconv(cur, dww, local(t), 7, bias=dwb, lnw=lnw, lnb=lnb, eps=blk.norm.eps, name=bn_ + ".conv_dw+norm")
-                    self.p.conv(local(t), w1, local(h), shift=b1, act=L.ACT_GELU, name=bn_ + ".mlp.fc1")
                     dst = view(out_full) if bi == len(st.blocks) - 1 else local(pp_[bi % 2])
-                    self.p.conv(local(h), w2, dst, shift=b2, res=cur, name=bn_ + ".mlp.fc2")
+                    if fused:   # stages 0-1 in bf16: the 4d-wide hidden tensor stays on chip (mlp_fused.hip)
+                        self.p.mlp_fused(local(t), cur, w1, b1, w2p[bi], b2, dst, name=bn_ + ".mlp(fused)")
+                    else:
+                        self.p.conv(local(t), w1, local(h), shift=b1, act=gelu, name=bn_ + ".mlp.fc1")
+                        self.p.conv(local(h), w2, dst, shift=b2, res=cur, name=bn_ + ".mlp.fc2")
                     cur = dst
-            for buf in [t, h] + pp_:
+            for buf in [t] + ([] if h is None else [h]) + pp_:
                 self.p.release(buf)
             self.p.release(a)        # stage input: stem / downsample output, never a feature
             a = out_full
@@ -596,10 +613,12 @@ class _Base(nn.Module):
 
     @torch.no_grad()
     def infer_and_detect(self, x: torch.Tensor, img_size: int, conf_th: float = 0.05, iou_th: float = 0.6, top_k: int = 100,
-                         masks: bool = True, side_stream: "torch.cuda.Stream" = None):
+                         masks: bool = True, side_stream: "torch.cuda.Stream" = None, own_outputs: bool = True):
         """`forward(x, "infer")` + `postprocess.detect_and_segment` as ONE scheduled step: the box decode and the
         per-image NMS (16 workgroups of latency-bound work) fork onto a side stream as soon as the Detect maps exist and
         run UNDER the Segment / Proto / cls launches; the mask assembly joins both.  Same results as the two calls.
+        `own_outputs=False` returns the raw maps / mc / protos / logits of the forward dict as VIEWS of the plan's buffers
+        (overwritten by the next call) instead of the fresh copies `forward()` hands out -- what a graph replay wants.
         Returns (forward dict, detections dict)."""
         from . import postprocess as pp
         det_flag, seg_flag = getattr(self, "detect", self.segment).training, self.segment.training
@@ -625,7 +644,7 @@ class _Base(nn.Module):
                 out["masks"], _ = pp.assemble_masks(c.protos.nchw(), c.mc.permute(0, 2, 1), k["keep_anchor"], k["counts"], (img_size, img_size))
             for t in (d["boxes"], d["best_score"], d["best_label"]):
                 t.record_stream(main)
-            return self._infer_dict(c), out
+            return self._infer_dict(c, own=own_outputs), out
         finally:
             if hasattr(self, "detect"):
                 self.detect.training = det_flag
@@ -655,15 +674,16 @@ class _Base(nn.Module):
 class ConvNeXtBiFPNYOLO(_Base):
     """Canonical variant, `/root/reference/src/main_model.py:300-393`."""
 
-    def _infer_dict(self, c):  # main_model.py:378-386
-        det_feats = [m.nchw().clone() for m in c.det_maps]
-        seg_feats = [m.nchw().clone() for m in c.seg_maps]
-        mc = c.mc.permute(0, 2, 1).clone()
-        logits = c.logits.clone()
+    def _infer_dict(self, c, own=True):  # main_model.py:378-386
+        cp = (lambda t: t.clone()) if own else (lambda t: t)   # own=False: views of plan buffers, valid until the next call
+        det_feats = [cp(m.nchw()) for m in c.det_maps]
+        seg_feats = [cp(m.nchw()) for m in c.seg_maps]
+        mc = cp(c.mc.permute(0, 2, 1))
+        logits = cp(c.logits)
         return {
             "detect_features": det_feats,
             "detect_preds_cat": self._preds_cat(c.det_maps, self.detect),
-            "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
+            "segment_protos": (seg_feats, mc, cp(c.protos.nchw())),
             "segment_preds_cat": self._preds_cat(c.seg_maps, self.segment, c.mc),
             "img_cls_logits": logits,
             "img_cls_probs": logits.softmax(dim=1),
@@ -705,14 +725,15 @@ class ConvNeXtBiFPNYOLO(_Base):
 class ConvNeXtBiFPNYOLOv2(_Base):
     """Segment-only variant, `/root/reference/src/main_modelv2.py:300-385`."""
 
-    def _infer_dict(self, c):  # main_modelv2.py:371-378
-        seg_feats = [m.nchw().clone() for m in c.seg_maps]
-        mc = c.mc.permute(0, 2, 1).clone()
+    def _infer_dict(self, c, own=True):  # main_modelv2.py:371-378
+        cp = (lambda t: t.clone()) if own else (lambda t: t)
+        seg_feats = [cp(m.nchw()) for m in c.seg_maps]
+        mc = cp(c.mc.permute(0, 2, 1))
         seg_cat = self._preds_cat(c.seg_maps, self.segment, c.mc)
-        logits = c.logits.clone()
+        logits = cp(c.logits)
         return {
             "detect_preds_cat": seg_cat[:, : 4 + self.nc_det],
-            "segment_protos": (seg_feats, mc, c.protos.nchw().clone()),
+            "segment_protos": (seg_feats, mc, cp(c.protos.nchw())),
             "segment_preds_cat": seg_cat,
             "img_cls_logits": logits,
             "img_cls_probs": logits.softmax(dim=1),

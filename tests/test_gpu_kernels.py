@@ -30,7 +30,7 @@ def run(plan):
     torch.cuda.synchronize()
 
 
-ACTS = {0: lambda v: v, 1: F.silu, 2: F.elu, 3: F.gelu}
+ACTS = {0: lambda v: v, 1: F.silu, 2: F.elu, 3: F.gelu, 4: F.gelu}  # 4 = polynomial GELU (|err| <= 2.3e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -40,6 +40,7 @@ ACTS = {0: lambda v: v, 1: F.silu, 2: F.elu, 3: F.gelu}
     (1, 20, 20, 128, 128, 3, 1, 1, 1, False, 0),
     (2, 9, 7, 96, 384, 1, 1, 0, 3, False, 0),        # ConvNeXt fc1 (+GELU), ragged pixel tile, TC=128
     (2, 9, 7, 384, 96, 1, 1, 0, 0, True, 0),         # ConvNeXt fc2 + layer-scale residual, TC=96
+    (2, 9, 7, 96, 384, 1, 1, 0, 4, False, 0),        # fc1 with the polynomial GELU of the bf16 mode
     (1, 16, 16, 96, 192, 2, 2, 0, 0, False, 0),      # downsample 2x2/2
     (1, 8, 8, 256, 2, 1, 1, 0, 0, False, 0),         # cls conv, K=2 (scalar epilogue)
     (1, 10, 10, 64, 32, 1, 1, 0, 1, False, 0),
@@ -261,3 +262,29 @@ def test_gap_fc(dtype):
     p.gap_fc(Act.of(nhwc(x).to(dtype)), w.to(DEV), b.to(DEV), y)
     run(p)
     assert (y.cpu() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("D,M", [(96, 1000), (192, 517), (96, 256)])
+def test_convnext_mlp_fused(D, M):
+    """mlp_fused.hip against torch: res + fc2'(GELU(fc1(t))) with bf16 storage of t, the hidden activations and the weights
+    (the unfused path rounds at the same points); ragged M exercises the tail masking."""
+    from multitask_bonetumor_yolo_amd.model import _permute_hidden
+    from multitask_bonetumor_yolo_amd import _lib as L
+    g = torch.Generator().manual_seed(D + M)
+    t = torch.randn(M, D, generator=g).bfloat16()
+    res = torch.randn(M, D, generator=g).bfloat16()
+    w1 = (torch.randn(4 * D, D, generator=g) / D ** 0.5).bfloat16()
+    w2 = (torch.randn(D, 4 * D, generator=g) / (4 * D) ** 0.5 * 0.1).bfloat16()
+    b1, b2 = torch.randn(4 * D, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    hid = torch.nn.functional.gelu(t.float() @ w1.float().t() + b1).bfloat16().float()
+    ref = res.float() + hid @ w2.float().t() + b2
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    dev = [v.to(DEV) for v in (t, res, w1, b1, _permute_hidden(w2), b2)]
+    lib = L.load()
+    rc = lib.mtbt_convnext_mlp_fused(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
+                                     dev[5].data_ptr(), y.data_ptr(), M, D, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < 0.03 * max(1.0, ref.abs().max().item()), err   # bf16 output rounding (2^-8 relative) dominates
+    assert ((y.float().cpu() - ref).norm() / ref.norm()).item() < 5e-3
