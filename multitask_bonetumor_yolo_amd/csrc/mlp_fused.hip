@@ -48,8 +48,8 @@ struct MlpP {
   ConvP ep;            // epilogue view: shift = b2', res, y, K = D
 };
 
-template <int D, int FP>
-__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpP p) {
+template <int D, int FP, int WPS>
+__global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   constexpr int KS1 = D / 32;            // k-steps of GEMM1
   constexpr int FC = D / 16;             // output-channel fragments of GEMM2
   constexpr int NCH = 4 * D / 32;        // hidden chunks
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(const MlpP p) {
   }
 }
 
-template <int D, int FP>
+template <int D, int FP, int WPS>
 int launch_mlp(const MlpP& p, hipStream_t s) {
   constexpr int P = 4 * FP * 16;
   constexpr int STAGE = 32 * D * 2 + D * 64;
@@ -224,10 +224,10 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     attr_set = true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<D, FP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<D, FP, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MTBT_ELAUNCH;
   }
-  hipLaunchKernelGGL((mlp_fused_kernel<D, FP>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -254,5 +254,8 @@ extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const voi
   e.scale = nullptr; e.shift = b2; e.K = D; e.ldy = D; e.ldr = D; e.act = MTBT_ACT_NONE;
   e.out_mode = MTBT_OUT_NHWC; e.out_f32 = 0; e.vec_ok = 1; e.M = (int)M;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return D == 96 ? launch_mlp<96, 4>(p, s) : launch_mlp<192, 2>(p, s);
+  // pixels per wave / waves per SIMD, measured (tools/mlp_probe.py): d = 96: 2 x 16 pixels at 4 waves per SIMD 100 us,
+  // 3 x 16 at 3: 116, 4 x 16 at 2: 139 -- the kernel's skeleton (input / residual loads, stores) is latency-bound, so
+  // residency beats the larger register tile; d = 192: 2 x 16 at 2: 110 us, 1 x 16 at 4: 125 (LDS-read bound).
+  return D == 96 ? launch_mlp<96, 2, 4>(p, s) : launch_mlp<192, 2, 2>(p, s);
 }

@@ -10,7 +10,7 @@ for D, M in [(96, 16 * 160 * 160), (192, 16 * 80 * 80)]:
     w1 = torch.randn(4 * D, D, device=dev).bfloat16() * 0.1; w2 = torch.randn(D, 4 * D, device=dev).bfloat16() * 0.05
     b1 = torch.zeros(4 * D, device=dev); b2 = torch.zeros(D, device=dev); y = torch.empty_like(t)
     out = []
-    for dbg in (0, 1, 6, 15, 15 + 16, 15 + 32):
+    for dbg in (0, 256, 512):
         os.environ["MTBT_MLP_DEBUG"] = str(dbg)
         s = torch.cuda.current_stream().cuda_stream
         f = lambda: lib.mtbt_convnext_mlp_fused(t.data_ptr(), res.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), M, D, s)
