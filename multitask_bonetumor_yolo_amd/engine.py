@@ -299,9 +299,10 @@ class Plan:
 
     def run_timed(self):
         """Replay with a HIP event pair around every launch (all on torch's current stream, which is the stream
-        the kernels are launched on).  Returns per-launch milliseconds, with the cost of an EMPTY event pair (calibrated in
-        the same pass: ~2 us of marker packets) subtracted so that the figures agree with rocprofv3's kernel durations.
-        Slower than run(); for roofline accounting."""
+        the kernels are launched on).  Returns per-launch milliseconds minus HALF the duration of an empty event pair
+        (calibrated in the same pass, ~2.5 us): uncorrected the figures sit ~5 % above rocprofv3's kernel durations of the same
+        launches, with the full pair subtracted ~7 % below; half the pair lands within ~1 %.  Slower than run(); for roofline
+        accounting."""
         s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         evs, empty = [], []
         for i, l in enumerate(self.launches):
@@ -318,7 +319,7 @@ class Plan:
                 L.check(rc, l.name)
             evs.append((a, b))
         torch.cuda.synchronize(self.device)
-        over = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2] if empty else 0.0
+        over = 0.5 * sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2] if empty else 0.0
         return [max(a.elapsed_time(b) - over, 0.0) for a, b in evs]
 
     # ---- helpers ----
