@@ -148,40 +148,49 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
   }
 }
 
-// LayerNorm over C, one wave per pixel, values held in registers between the two passes.
-template <typename T, int MAXV>
+// LayerNorm over C, values held in registers between the two passes.  A pixel is handled by a group of LP lanes (LP = 16,
+// 32 or 64: the power of two covering C/8 eight-channel pieces), so a wave normalises 64/LP pixels at once -- with one
+// wave per pixel the 96-channel downsample norm used 12 of 64 lanes (104 us for 157 MB).  MAXV = pieces per lane.
+template <int LP> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int MAXV, int LP>
 __global__ void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                  float eps, T* __restrict__ y, long pixels, int C) {
-  const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (pix >= pixels) return;
+  constexpr int PPW = 64 / LP;                       // pixels per wave
+  const int lane = threadIdx.x & 63, gl = lane % LP;
+  const long pix = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PPW + lane / LP;
+  const bool live = pix < pixels;                    // (whole groups: the shuffles below stay inside a group)
   const int CH8 = C >> 3;
   float v[MAXV][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int ch = lane + i * 64;
-    if (ch < CH8) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
       ld8<T>(x + pix * C + ch * 8, v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
   }
-  const float mean = wave_sum(s) / C;
+  const float mean = group_sum<LP>(s) / C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int ch = lane + i * 64;
-    if (ch < CH8) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  const float rstd = rsqrtf(group_sum<LP>(q) / C + eps);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int ch = lane + i * 64;
-    if (ch < CH8) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
       float gw[8], gb[8], o[8];
       ld8<float>(w + ch * 8, gw);
       ld8<float>(b + ch * 8, gb);
@@ -352,15 +361,20 @@ extern "C" int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b
                                    int C, int dtype, void* stream) {
   if (!x || !w || !b || !y || pixels <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
   if (!aligned16(x) || !aligned16(y) || !aligned16(w) || !aligned16(b)) return MTBT_EALIGN;
-  const long blocks = (pixels + 3) / 4;
-  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int CH8 = C / 8;
-#define LN_LAUNCH(T, MAXV) \
-  hipLaunchKernelGGL((layernorm_kernel<T, MAXV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, w, b, eps, (T*)y, (long)pixels, C)
-  if (dtype == MTBT_F32) { if (CH8 <= 64) LN_LAUNCH(float, 1); else if (CH8 <= 128) LN_LAUNCH(float, 2); else LN_LAUNCH(float, 4); }
-  else if (dtype == MTBT_BF16) { if (CH8 <= 64) LN_LAUNCH(bf16_t, 1); else if (CH8 <= 128) LN_LAUNCH(bf16_t, 2); else LN_LAUNCH(bf16_t, 4); }
+  const int LP = CH8 <= 16 ? 16 : (CH8 <= 32 ? 32 : 64);   // lanes per pixel
+  const long blocks = (pixels + 4 * (64 / LP) - 1) / (4 * (64 / LP));
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+#define LN_LAUNCH(T, MAXV, LPV) \
+  hipLaunchKernelGGL((layernorm_kernel<T, MAXV, LPV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, w, b, eps, (T*)y, (long)pixels, C)
+#define LN_BY_C(T) \
+  do { if (LP == 16) LN_LAUNCH(T, 1, 16); else if (LP == 32) LN_LAUNCH(T, 1, 32); else if (CH8 <= 64) LN_LAUNCH(T, 1, 64); \
+       else if (CH8 <= 128) LN_LAUNCH(T, 2, 64); else LN_LAUNCH(T, 4, 64); } while (0)
+  if (dtype == MTBT_F32) LN_BY_C(float);
+  else if (dtype == MTBT_BF16) LN_BY_C(bf16_t);
   else return MTBT_EINVAL;
+#undef LN_BY_C
 #undef LN_LAUNCH
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;

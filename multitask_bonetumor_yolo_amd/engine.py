@@ -145,21 +145,29 @@ class Plan:
         """Issue the plan.  Default: the launches are spread over `lanes()` HIP streams following their data
         dependencies (see schedule()); lane 0 is the caller's current stream, the others fork from it at the start and
         join it at the end, so to the caller the plan still looks like work on its current stream (and a HIP-graph
-        capture of that stream records the lanes as parallel branches).  `marks` = launch indices; returns one event per
-        lane that covers them (recorded after the last marked launch of that lane) so that a consumer stream can start
-        as soon as those launches are done.  A sub-range [start, end) or an explicit `stream` runs sequentially."""
+        capture of that stream records the lanes as parallel branches).  `marks` = launch indices (or a dict of named
+        index lists); returns, per list, one event per lane that covers them (recorded after the last marked launch of that
+        lane) so that a consumer stream can start as soon as those launches are done.  A sub-range [start, end) or an
+        explicit `stream` runs sequentially."""
+        groups = marks if isinstance(marks, dict) else ({"_": list(marks)} if marks else {})
+        unwrap = (lambda r: r) if isinstance(marks, dict) else (lambda r: r.get("_", []))
         sequential = stream is not None or start != 0 or (end is not None and end != len(self.launches)) or self.lanes() <= 1
         if sequential:
             s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream)
-            last_mark, evs = (max(marks) if marks else -1), []
+            at = {}
+            for name, idx in groups.items():
+                if idx:
+                    at.setdefault(max(idx), []).append(name)
+            out = {name: [] for name in groups}
             for i, l in enumerate(self.launches[start:end], start):
                 rc = l.fn(*l.args, s)
                 if rc != 0:
                     L.check(rc, l.name)
-                if i == last_mark:
-                    evs.append(torch.cuda.Event())
-                    evs[0].record(torch.cuda.current_stream(self.device))
-            return evs
+                for name in at.get(i, ()):
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    out[name].append(ev)
+            return unwrap(out)
         sch = self.schedule()
         if sch.events is None:
             sch.events = [torch.cuda.Event() for _ in range(sch.n_events)]
@@ -173,11 +181,15 @@ class Plan:
         used = sch.used_side_lanes  # lanes that got no launch stay out of the fork / join (and out of a graph capture)
         for k in used:
             streams[k].wait_event(fork)
-        mark_last = {}
-        for i in (marks or ()):
-            ln = sch.lane[i]
-            mark_last[ln] = max(mark_last.get(ln, -1), i)
-        mark_at = {i: torch.cuda.Event() for i in mark_last.values()}
+        mark_at, out = {}, {name: [] for name in groups}   # launch index -> [(group, event)]
+        for name, idx in groups.items():
+            last = {}
+            for i in idx:
+                last[sch.lane[i]] = max(last.get(sch.lane[i], -1), i)
+            for i in last.values():
+                ev = torch.cuda.Event()
+                mark_at.setdefault(i, []).append(ev)
+                out[name].append(ev)
         launches = self.launches
         import os
         serial = os.environ.get("MTBT_LANE_SERIAL") == "1"  # dev: total order across lanes (no two launches overlap)
@@ -198,12 +210,12 @@ class Plan:
             e = sch.records[i]
             if e >= 0:
                 sch.events[e].record(streams[ln])
-            if i in mark_at:
-                mark_at[i].record(streams[ln])
+            for ev in mark_at.get(i, ()):
+                ev.record(streams[ln])
         for k in used:
             sch.join_events[k - 1].record(streams[k])
             main.wait_event(sch.join_events[k - 1])
-        return list(mark_at.values())
+        return unwrap(out)
 
     def lanes(self) -> int:
         import os
