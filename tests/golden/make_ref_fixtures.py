@@ -139,6 +139,59 @@ def main():
             feats = [r(2, 8, 6, 5) for _ in range(n)]
             cases[f"WeightedAdd_{n}"] = {"w": wa.w.detach().clone(), "inputs": feats, "output": wa(feats).clone()}
 
+    # MultiTaskLitModel._multitask_loss (running_main_v3.py:232-387), called unbound on a stand-in `self` that carries exactly
+    # what the method reads (hparams, the four torch loss modules of :189-192, the 1x1 projector of :186, reg_max)
+    if ref_train is not None:
+        import torch.nn as nn
+        S, B, NC = 64, 3, 2
+
+        def make_self(training, smoothing):
+            hp = types.SimpleNamespace(img_size=S, nc_det=NC, proto_ch=32, loss_weight_seg=1.0, loss_weight_box_iou=2.0,
+                                       loss_weight_dfl=1.5, loss_weight_cls_det=0.5, loss_weight_img_cls=1.0,
+                                       iou_match_thresh=0.5, det_label_smoothing=smoothing)
+            proj = nn.Conv2d(32, 1, kernel_size=1)
+            with torch.no_grad():
+                proj.weight.copy_(torch.randn(1, 32, 1, 1, generator=torch.Generator().manual_seed(5)) * 0.3)
+                proj.bias.fill_(-0.2)
+            return types.SimpleNamespace(hparams=hp, img_cls_loss_fn=nn.CrossEntropyLoss(), seg_loss_fn=nn.BCEWithLogitsLoss(),
+                                         det_cls_loss_fn=nn.BCEWithLogitsLoss(reduction="sum"),
+                                         det_dfl_loss_fn=nn.CrossEntropyLoss(reduction="none"), seg_proto_projector=proj,
+                                         reg_max=16, project=None, training=training, temp_matched_preds_for_cm=[],
+                                         seg_logits_for_logging=None), proj
+
+        # GT boxes (batch_idx, cls, cx, cy, w, h) normalised; image 1 has no box.  The raw maps are steered so that some
+        # anchors really overlap a GT box by more than 0.5 (random maps alone would give no positive match).
+        gt = torch.tensor([[0, 1, 0.30, 0.35, 0.40, 0.30], [0, 0, 0.70, 0.70, 0.30, 0.35], [2, 1, 0.50, 0.50, 0.60, 0.50]])
+        det = []
+        for h in (8, 4, 2):
+            m = r(B, 64 + NC, h, h) * 0.5
+            stride = S / h
+            for row in gt:
+                b, cx, cy, w_, h_ = int(row[0]), row[2] * S, row[3] * S, row[4] * S, row[5] * S
+                for yy in range(h):
+                    for xx in range(h):
+                        ax, ay = (xx + 0.5) * stride, (yy + 0.5) * stride
+                        ltrb = torch.tensor([ax - (cx - w_ / 2), ay - (cy - h_ / 2), (cx + w_ / 2) - ax, (cy + h_ / 2) - ay]) / stride
+                        if ltrb.min() > 0.3 and ltrb.max() < 14.0:
+                            for k in range(4):   # peak the 16-bin distribution around the target distance
+                                bins = torch.arange(16.0)
+                                m[b, 16 * k:16 * k + 16, yy, xx] += 6.0 * torch.exp(-0.5 * (bins - ltrb[k]) ** 2 / 0.3)
+            det.append(m)
+        protos = r(B, 32, 16, 16)
+        logits = r(B, 2)
+        gt_masks = (torch.rand(B, 1, S, S, generator=gen) > 0.6).float()
+        gt_cls = torch.tensor([0, 1, 1])
+        for name, training, smoothing in (("loss_train", True, 0.1), ("loss_train_nosmooth", True, 0.0), ("loss_eval", False, 0.1)):
+            fake, proj = make_self(training, smoothing)
+            with torch.no_grad():
+                out = ref_train.MultiTaskLitModel._multitask_loss(fake, [d.clone() for d in det], (None, None, protos.clone()),
+                                                                  logits.clone(), gt.clone(), gt_masks.clone(), gt_cls.clone())
+            cases[name] = {"det": det, "protos": protos, "logits": logits, "gt_boxes": gt, "gt_masks": gt_masks, "gt_cls": gt_cls,
+                           "proj_w": proj.weight.detach().clone(), "proj_b": proj.bias.detach().clone(), "training": training,
+                           "smoothing": smoothing, "img_size": S, "nc_det": NC,
+                           "output": [o.detach().clone() if isinstance(o, torch.Tensor) else torch.tensor(float(o)) for o in out]}
+            print(name, [round(float(o), 5) for o in cases[name]["output"]])
+
     torch.save(cases, OUT)
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", list(cases))
 

@@ -76,3 +76,17 @@ def test_weighted_add_of_oldest_variant_bit_exact(cases):
         with torch.no_grad():
             m.w.copy_(c["w"])
             assert torch.equal(m(c["inputs"]), c["output"])
+
+
+@pytest.mark.parametrize("name", ["loss_train", "loss_train_nosmooth", "loss_eval"])
+def test_multitask_loss_matches_reference_method(cases, name):
+    """oracle.loss.multitask_loss against MultiTaskLitModel._multitask_loss itself (running_main_v3.py:232-387), incl. the
+    reference's column-concatenated GT boxes (two boxes in image 0), an image without boxes, label smoothing on / off and
+    the eval-mode tuple."""
+    from oracle.loss import multitask_loss
+    c = cases[name]
+    out = multitask_loss(c["det"], c["protos"], c["logits"], c["gt_boxes"], c["gt_masks"], c["gt_cls"], c["proj_w"], c["proj_b"],
+                         img_size=c["img_size"], nc_det=c["nc_det"], label_smoothing=c["smoothing"], training=c["training"])
+    assert len(out) == len(c["output"]) and len(out) == (8 if c["training"] else 6)
+    for a, b in zip(out, c["output"]):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-6), (name, float(a), float(b))
