@@ -216,6 +216,45 @@ typedef struct mtbt_mask_args {
 
 int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multitask loss VALUE (forward only), MultiTaskLitModel._multitask_loss, running_main_v3.py:232-387:
+ *   per (image, anchor): trainer decode (:268-290), IoU against the image's GT boxes (:316), positives = max IoU >
+ *   iou_thresh (:319-321), sum(1 - IoU) (:331), BCE-with-logits(sum) of the class logits against one-hot /
+ *   label-smoothed targets (:334-346), two-bin DFL cross-entropy (:351-367); segmentation BCE-with-logits (mean over
+ *   seg_n logits, :257); image-classification cross-entropy (:237); normalisation by the batch's positive count (batch
+ *   size if none, :371) and the weighted total (:377-383).
+ * map[l]: raw Detect maps [N,h_l,w_l,4*reg_max+nc] f32 NHWC (pixel stride map_pixel_stride[l]).  GT boxes grouped by image:
+ * gt_xyxy [G][4] pixels, gt_cls [G], gt_off [N+1] (image n owns [gt_off[n], gt_off[n+1])).  seg_logits / seg_targets:
+ * seg_n floats each (may be NULL with seg_n = 0); *seg_bias (device scalar, optional) is added to every seg logit.  img_logits [N][n_img_classes] f32, img_gt [N] int64.
+ * out[8] = total, seg, box, dfl, cls_det, img_cls, #positives, mean matched IoU.  Deterministic; no host synchronisation.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtbt_loss_args {
+  const float* map[3];
+  int32_t h[3], w[3];
+  int32_t map_pixel_stride[3];
+  int32_t n_levels, N, nc, reg_max;
+  float img_size;
+  const float* gt_xyxy;
+  const int32_t* gt_cls;
+  const int32_t* gt_off;
+  float iou_thresh, label_smoothing;
+  int32_t training; /* label smoothing applies in training mode only (:337) */
+  const float* seg_logits;
+  const float* seg_targets;
+  const float* seg_bias; /* optional device scalar added to every seg logit (the projector's bias), may be NULL */
+  int64_t seg_n;
+  const float* img_logits;
+  const int64_t* img_gt;
+  int32_t n_img_classes;
+  float w_seg, w_box, w_dfl, w_cls, w_img;
+  float* workspace;
+  int64_t workspace_bytes; /* >= mtbt_loss_workspace_bytes(N, A, seg_n) */
+  float* out;
+} mtbt_loss_args;
+
+int64_t mtbt_loss_workspace_bytes(int N, int A, int64_t seg_n);
+int mtbt_multitask_loss(const mtbt_loss_args* a, void* stream);
+
 /* Fused ConvNeXt MLP (timm Mlp fc1 -> GELU -> fc2 with the layer-scale folded, + residual) for d in {96, 192}, bf16 only:
  *   y[p][:] = res[p][:] + W2' . GELU(W1 . t[p][:] + b1) + b2'      (the 4d-wide hidden tensor never leaves the chip)
  * t, res, y: dense [M][d] bf16; w1 [4d][d] bf16; b1 [4d] f32; b2 [d] f32; w2p [d][4d] bf16 whose columns are reordered

@@ -2,10 +2,12 @@
 
     from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO          # == reference main_model.ConvNeXtBiFPNYOLO
     from multitask_bonetumor_yolo_amd import postprocess                 # decode / NMS / masks on the GPU
+    from multitask_bonetumor_yolo_amd import multitask_loss              # == MultiTaskLitModel._multitask_loss (value)
 
 The HIP library (csrc/libmtbt_hip.so, C ABI in include/mtbt_hip.h) is built by
 `python -m multitask_bonetumor_yolo_amd.build`; nothing here falls back to the CPU.
 """
 from . import postprocess  # noqa: F401
+from .loss import multitask_loss  # noqa: F401
 from .graphed import GraphedInference  # noqa: F401
 from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv0, ConvNeXtBiFPNYOLOv2, init_synthetic_  # noqa: F401

@@ -55,6 +55,19 @@ class MaskArgs(C.Structure):
     ]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [
+        ("map", C.c_void_p * 3), ("h", C.c_int32 * 3), ("w", C.c_int32 * 3), ("map_pixel_stride", C.c_int32 * 3),
+        ("n_levels", C.c_int32), ("N", C.c_int32), ("nc", C.c_int32), ("reg_max", C.c_int32), ("img_size", C.c_float),
+        ("gt_xyxy", C.c_void_p), ("gt_cls", C.c_void_p), ("gt_off", C.c_void_p),
+        ("iou_thresh", C.c_float), ("label_smoothing", C.c_float), ("training", C.c_int32),
+        ("seg_logits", C.c_void_p), ("seg_targets", C.c_void_p), ("seg_bias", C.c_void_p), ("seg_n", C.c_int64),
+        ("img_logits", C.c_void_p), ("img_gt", C.c_void_p), ("n_img_classes", C.c_int32),
+        ("w_seg", C.c_float), ("w_box", C.c_float), ("w_dfl", C.c_float), ("w_cls", C.c_float), ("w_img", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("out", C.c_void_p),
+    ]
+
+
 # every symbol include/mtbt_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "mtbt_abi_version": (C.c_int, []),
@@ -74,6 +87,8 @@ SYMBOLS = {
     "mtbt_nms_batched": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int]
                          + [C.c_void_p] * 8 + [C.c_int64, C.c_void_p]),
     "mtbt_mask_assemble": (C.c_int, [C.POINTER(MaskArgs), C.c_void_p]),
+    "mtbt_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
+    "mtbt_multitask_loss": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "mtbt_convnext_mlp_fused": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mtbt_bbox_iou_pairwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

@@ -44,6 +44,8 @@ def test_struct_layouts_match_header(tmp_path):
         "mtbt_conv_args": (L.ConvArgs, ["x", "res", "x_batch_stride", "x_pixel_stride", "N", "K", "Ho", "dtype", "tile_hint"]),
         "mtbt_fuse_args": (L.FuseArgs, ["x", "wgt", "resample", "n_in", "y", "N", "add_weight_bug"]),
         "mtbt_decode_args": (L.DecodeArgs, ["map", "h", "map_pixel_stride", "stride", "n_levels", "xywh", "boxes", "preds_cat", "cat_stride"]),
+        "mtbt_loss_args": (L.LossArgs, ["map", "h", "img_size", "gt_xyxy", "iou_thresh", "training", "seg_logits", "seg_bias", "seg_n", "img_gt",
+                                        "n_img_classes", "w_img", "workspace", "workspace_bytes", "out"]),
         "mtbt_mask_args": (L.MaskArgs, ["protos", "coeff_batch_stride", "gather_idx", "bias", "N", "Wout", "logits", "masks"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mtbt_hip.h"', 'int main(void){']
