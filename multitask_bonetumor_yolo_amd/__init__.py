@@ -9,5 +9,6 @@ The HIP library (csrc/libmtbt_hip.so, C ABI in include/mtbt_hip.h) is built by
 """
 from . import postprocess  # noqa: F401
 from .loss import multitask_loss  # noqa: F401
+from .checkpoints import load_pretrained_heads, strip_lightning_prefix  # noqa: F401
 from .graphed import GraphedInference  # noqa: F401
 from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv0, ConvNeXtBiFPNYOLOv2, init_synthetic_  # noqa: F401

@@ -163,3 +163,40 @@ def test_plan_dependencies_and_lanes(monkeypatch):
                 covered = any(s.records[k] in s.waits[m] for k in range(j, i) if s.lane[k] == s.lane[j] and s.records[k] >= 0
                               for m in range(k + 1, i + 1) if s.lane[m] == s.lane[i])
                 assert covered, (i, j)
+
+
+def test_load_pretrained_heads_from_flat_state_dict(tmp_path, capsys):
+    """main_model.py:399-603 semantics on a flat state dict with ultralytics key names: last head block wins, name + shape
+    matching, parameters only, the reference's report lines."""
+    from multitask_bonetumor_yolo_amd import load_pretrained_heads, strip_lightning_prefix
+    from oracle.heads import Detect as ODetect, Segment as OSegment
+    torch.manual_seed(0)
+    src_det, src_seg = ODetect(nc=2, ch=[256] * 3), OSegment(nc=2, nm=32, npr=256, ch=[256] * 3)
+    other = ODetect(nc=5, ch=[256] * 3)                                   # an earlier block with another class count
+    sd_det = {f"model.9.{k}": v for k, v in other.state_dict().items()}
+    sd_det.update({f"model.22.{k}": v for k, v in src_det.state_dict().items()})
+    sd_seg = {f"model.model.23.{k}": v for k, v in src_seg.state_dict().items()}
+    path = tmp_path / "seg_state.pt"
+    torch.save(sd_seg, path)
+    m = ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)
+    bn_before = m.detect.cv2[0][0].bn.running_var.clone()
+    rep = load_pretrained_heads(m, detect_ckpt_path=sd_det, segment_ckpt_path=str(path))
+    n_det, n_seg = len(list(m.detect.named_parameters())), len(list(m.segment.named_parameters()))
+    # (the reference walks Segment as cv4, proto, cv2, cv3 -- `dfl.conv.weight` is not part of its Segment report)
+    assert rep["detect"] == (n_det, n_det) and rep["segment"] == (n_seg - 1, n_seg - 1)
+    assert torch.equal(m.detect.cv3[1][2].weight, src_det.cv3[1][2].weight) and torch.equal(m.segment.proto.upsample.weight, src_seg.proto.upsample.weight)
+    assert torch.equal(m.detect.cv2[0][0].bn.running_var, bn_before)     # buffers untouched, like named_parameters() in the reference
+    out = capsys.readouterr().out
+    assert f"Detect head          : {n_det}/{n_det} tensors copied" in out and "Segment head" in out
+    # class-count mismatch: only the nc-dependent tensors are skipped
+    rep2 = load_pretrained_heads(ConvNeXtBiFPNYOLO(3, 2, pretrained_backbone=False), detect_ckpt_path=sd_det)
+    assert rep2["detect"][0] == n_det - 6 and "Shape mismatch" in capsys.readouterr().out
+    # a pickled object is refused with instructions, never unpickled
+    import pickle
+    bad = tmp_path / "model_object.pt"
+    with open(bad, "wb") as f:
+        pickle.dump({"model": object}, f)
+    with pytest.raises(RuntimeError, match="not a plain state dict"):
+        load_pretrained_heads(m, detect_ckpt_path=str(bad))
+    lit = {"net.cls_fc.weight": torch.zeros(2, 256), "seg_proto_projector.weight": torch.zeros(1, 32, 1, 1)}
+    assert list(strip_lightning_prefix(lit)) == ["cls_fc.weight"]
