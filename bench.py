@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--img", type=int, default=IMG, help="image side (default 640 = the benchmark configuration; 1280 = BASELINE configs[4]'s shape)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the ~220 launches of a step eagerly instead of replaying a HIP graph")
@@ -91,6 +92,7 @@ def main():
     model = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     B = args.batch
+    globals()["IMG"] = args.img
     x = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(rank)).to(dev)  # resident in HBM
 
     def eager_step():
@@ -213,7 +215,7 @@ def main():
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch-{B}/GPU {IMG}x{IMG} multitask inference (ConvNeXt-T + C2f-BiFPN + Detect/Segment/cls) "
+            "config": {"workload": f"{'configs[1]' if (B, IMG) == (BATCH_PER_GPU, 640) else 'side measurement'}: batch-{B}/GPU {IMG}x{IMG} multitask inference (ConvNeXt-T + C2f-BiFPN + Detect/Segment/cls) "
                                    f"+ decode + per-image NMS(top-100) + mask assembly; random-init weights",
                        "batch_per_gpu": B, "img": IMG, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "kept_boxes_per_image": float(res["counts"].float().mean().item())},
