@@ -112,7 +112,7 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
     if ((pol & 4) && !((a->tile_hint >> 26) & 1) && a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->H % 16 == 0 &&
         a->W % 16 == 0 && a->out_mode == MTBT_OUT_NHWC && a->C % (128 / es) == 0 && a->K > 32 &&
         (long)a->H * a->W * a->x_pixel_stride * es < 0x7fff0000L && (long)128 * 9 * a->C * es < 0x7fff0000L) {
-      const int tc = a->K >= 96 ? 128 : 64;
+      const int tc = (a->K >= 96 && !getenv("MTBT_DIRECT_TC64")) ? 128 : 64;
       return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s);
     }
   }

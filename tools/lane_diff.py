@@ -7,7 +7,8 @@ os.environ["MTBT_LANES"] = "1"
 from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, init_synthetic_
 dev = torch.device("cuda:0")
 m = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval().set_compute_dtype(torch.bfloat16)
-x = torch.rand(16, 3, 640, 640, device=dev)
+B, S = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (16, 640)
+x = torch.rand(B, 3, S, S, device=dev)
 c = m.compile(x); m._bind_input(c, x)
 p = c.plan
 L = p.launches
