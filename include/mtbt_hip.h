@@ -78,7 +78,8 @@ typedef struct mtbt_conv_args {
   int32_t out_dtype;   /* dtype of y: == dtype, or MTBT_F32 */
   int32_t act;         /* MTBT_ACT_* */
   int32_t out_mode;    /* MTBT_OUT_* */
-  int32_t tile_hint;   /* 0 = heuristic; else (TC<<16)|TP to force a tile (tests / tuning) */
+  int32_t tile_hint;   /* 0 = heuristic; else (TC<<16)|TP to force a tile (tests / tuning); bit 25 = row-reuse direct 3x3
+                          kernel, bit 26 = keep a 3x3 on the implicit-GEMM kernel, bit 27 = 64-byte K-steps, bits 28-30 = stages */
 } mtbt_conv_args;
 
 int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream);

@@ -112,12 +112,13 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
     if ((pol & 4) && !((a->tile_hint >> 26) & 1) && a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->H % 16 == 0 &&
         a->W % 16 == 0 && a->out_mode == MTBT_OUT_NHWC && a->C % (128 / es) == 0 && a->K > 32 &&
         (long)a->H * a->W * a->x_pixel_stride * es < 0x7fff0000L && (long)128 * 9 * a->C * es < 0x7fff0000L) {
-      const int tc = (a->K >= 96 && !getenv("MTBT_DIRECT_TC64")) ? 128 : 64;
+      int tc = (a->K >= 96 && !getenv("MTBT_DIRECT_TC64")) ? 128 : 64;
+      if ((pol & 8) || ((a->tile_hint >> 25) & 1)) tc |= 0x1000;  // row-reuse variant (conv3x3_rr_kernel): policy bit 3 / hint bit 25
       return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s);
     }
   }
   int TC, TP, nbuf = 0;
-  if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x3ff; TP = a->tile_hint & 0xffff; }
+  if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x1ff; TP = a->tile_hint & 0xffff; }
   int narrow = (a->tile_hint >> 27) & 1;  // hint bit 27: force 64-byte K-steps
   if (!a->tile_hint || !TC || !TP) pick_tile(a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow);
   const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;

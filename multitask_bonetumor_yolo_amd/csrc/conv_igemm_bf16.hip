@@ -14,6 +14,8 @@ int mtbt_conv_dispatch_bf16(const ConvP& p, int TC, int TP, int wide, int nbuf, 
 }
 
 int mtbt_conv3x3_direct_bf16(const ConvP& p, int TC, hipStream_t s) {
+  if (TC == (128 | 0x1000)) return launch_direct3x3_rr<bf16_t, 128>(p, s);
+  if (TC == (64 | 0x1000)) return launch_direct3x3_rr<bf16_t, 64>(p, s);
   if (TC == 128) return launch_direct3x3<bf16_t, 128>(p, s);
   if (TC == 64) return launch_direct3x3<bf16_t, 64>(p, s);
   return MTBT_EINVAL;

@@ -8,6 +8,8 @@ int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, h
 }
 
 int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s) {
+  if (TC == (128 | 0x1000)) return launch_direct3x3_rr<float, 128>(p, s);
+  if (TC == (64 | 0x1000)) return launch_direct3x3_rr<float, 64>(p, s);
   if (TC == 128) return launch_direct3x3<float, 128>(p, s);
   if (TC == 64) return launch_direct3x3<float, 64>(p, s);
   return MTBT_EINVAL;

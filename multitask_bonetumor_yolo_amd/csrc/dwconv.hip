@@ -91,6 +91,9 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
   // LayerNorm scratch: its own region when C <= 128 (the next tile's DMA is already landing in `tile` during the
   // epilogue); with several chunks it reuses the tile (LDS would otherwise not fit two workgroups per CU)
   constexpr int REDOFF = MAXCH == 1 ? TILEB : 0;
+  // several chunks: the chunk's KS*KS taps ride along with the halo tile ([tap][CC] T right behind it, PXI taps per
+  // DMA wave-instruction) -- read row by row from L2 instead, each filter row waited ~1 us for its taps
+  constexpr int NTI = (KS * KS + PXI - 1) / PXI;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -157,6 +160,16 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
       const unsigned vo = (unsigned)(ix0 + lane / PARTS) < (unsigned)W ? vlane + (unsigned)((ix0 * C + cb) * ES) : 0x80000000u;
       if (!(dbg & 2)) lds_dma16(srd, vo, 0, __builtin_amdgcn_readfirstlane(lds0 + (row * IWP + seg * PXI) * PIXB));
     }
+    if (MAXCH > 1) {
+      srd_t wsrd = make_srd(w);
+      wsrd.z = __builtin_amdgcn_readfirstlane((unsigned)(KS * KS * C * ES));   // taps past the last read as zeros
+#pragma unroll
+      for (int d = 0; d < (NTI + NW - 1) / NW; ++d) {
+        const int j = d * NW + wave_u;
+        if (NTI % NW != 0 && j >= NTI) break;
+        lds_dma16(wsrd, vlane + (unsigned)(cb * ES), j * PXI * C * ES, __builtin_amdgcn_readfirstlane(lds0 + TILEB + j * 1024));
+      }
+    }
   };
   bool first = true;
 
@@ -194,10 +207,8 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
         auto taps = [&](int ky) {
           // scalar base + one shared lane offset.  The empty asm makes the row's base opaque HERE: otherwise the addresses
           // of all 49 x chunks taps are loop-invariant, get hoisted out of the tile loop and spill.
-          const T* rb = wb + ky * KS * C;
-          asm volatile("" : "+s"(rb));
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) wrow[ky % 3][kx] = Pair<T>::ld(rb + kx * C + lane2);
+          for (int kx = 0; kx < KS; ++kx) wrow[ky % 3][kx] = Pair<T>::ld(smem + TILEB + (ky * KS + kx) * PIXB + lane2 * ES);
         };
         auto inputs = [&](int r) {
 #pragma unroll
@@ -323,7 +334,7 @@ int launch_dw(const void* x, const void* w, const float* bias, const float* lnw,
   constexpr int NT = (TH / 2) * (TW / XB) * 64;
   constexpr int PARTS = CC * (int)sizeof(T) / 16, PXI = 64 / PARTS, IWP = ((TW + KS - 1 + PXI - 1) / PXI) * PXI;
   constexpr int lds_tile = (TH + KS - 1) * IWP * CC * (int)sizeof(T), lds_red = LN ? (NT / 64) * (16 * 64 + 16) * 4 : 0;
-  constexpr int lds_taps = 0;
+  constexpr int lds_taps = MAXCH == 1 ? 0 : ((KS * KS + PXI - 1) / PXI) * 1024;
   constexpr int lds = MAXCH == 1 ? lds_tile + lds_red : (lds_tile + lds_taps > lds_red ? lds_tile + lds_taps : lds_red);
   static_assert(lds <= 160 * 1024, "LDS");
   const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);

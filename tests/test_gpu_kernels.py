@@ -57,6 +57,9 @@ ACTS = {0: lambda v: v, 1: F.silu, 2: F.elu, 3: F.gelu, 4: F.gelu}  # 4 = polyno
     (1, 16, 32, 64, 64, 3, 1, 1, 2, False, 0),       # direct 3x3, TC=64, single channel chunk
     (1, 48, 16, 192, 96, 3, 1, 1, 1, False, 0),      # direct 3x3, K=96 (ragged channel tile), 3 chunks
     (2, 32, 48, 128, 256, 3, 1, 1, 1, True, 1 << 26),  # same shape forced onto the implicit-GEMM kernel
+    (2, 32, 48, 128, 256, 3, 1, 1, 1, True, 1 << 25),  # ... and onto the row-reuse direct kernel (TC=128, 4 slabs)
+    (1, 16, 32, 64, 64, 3, 1, 1, 2, False, 1 << 25),   # row-reuse, TC=64, 2 slabs
+    (1, 48, 16, 96, 96, 3, 1, 1, 1, False, 1 << 25),   # row-reuse, ragged channel tile, odd slab count (3)
 ])
 def test_conv_igemm(dtype, cfg):
     N, H, W, Cin, K, k, st, pad, act, use_res, hint = cfg
