@@ -269,6 +269,23 @@ int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, cons
  * no-op (the reference returns an empty/zero matrix). */
 int mtbt_bbox_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, float eps, float* out, void* stream);
 
+/* Input pipeline of one batch (dataset_btxrdv2.py:109-166: `_letterbox`, BGR->RGB, /255, HWC->CHW, mask binarise), SURVEY §8f N2.
+ * images: HOST array of `count` descriptors of DEVICE buffers (decoded 8-bit BGR image as cv2.imread returns it, optional
+ * 8-bit grayscale mask of the same size).  Per image: scale = S / max(H0, W0), new = max(1, int(dim * scale)),
+ * image resized like cv2.resize(INTER_LINEAR) (OpenCV's 8-bit fixed-point path), mask like INTER_NEAREST, both placed
+ * top-left; image padded with 114, mask with 0.  out_images [count][3][S][S] f32 RGB in [0,1]; out_masks
+ * [count][1][S][S] f32 in {0,1} (NULL = skip; a NULL descriptor mask gives zeros); out_scales HOST [count] (NULL = skip):
+ * the letterbox scale the caller applies to its YOLO-txt boxes (:200-203).  S % 4 == 0. */
+typedef struct {
+  const uint8_t* bgr;
+  const uint8_t* mask;
+  int32_t height, width;
+  int64_t row_stride;       /* bytes between image rows (>= 3 * width) */
+  int64_t mask_row_stride;  /* bytes between mask rows (>= width) */
+} mtbt_raw_image;
+int mtbt_letterbox_batch(const mtbt_raw_image* images, int count, int img_size, float* out_images, float* out_masks,
+                         double* out_scales, void* stream);
+
 /* dtype / layout helpers on the boundary */
 int mtbt_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 

@@ -69,6 +69,11 @@ class LossArgs(C.Structure):
 
 
 # every symbol include/mtbt_hip.h declares: name -> (restype, argtypes)
+class RawImage(C.Structure):  # mtbt_raw_image
+    _fields_ = [("bgr", C.c_void_p), ("mask", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32),
+                ("row_stride", C.c_int64), ("mask_row_stride", C.c_int64)]
+
+
 SYMBOLS = {
     "mtbt_abi_version": (C.c_int, []),
     "mtbt_target_arch": (C.c_char_p, []),
@@ -91,6 +96,7 @@ SYMBOLS = {
     "mtbt_multitask_loss": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "mtbt_convnext_mlp_fused": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mtbt_bbox_iou_pairwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "mtbt_letterbox_batch": (C.c_int, [C.POINTER(RawImage), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 
