@@ -286,6 +286,14 @@ typedef struct {
 int mtbt_letterbox_batch(const mtbt_raw_image* images, int count, int img_size, float* out_images, float* out_masks,
                          double* out_scales, void* stream);
 
+/* Segmentation metric accumulators (running_main_v3.py:466-498 feeding the torchmetrics objects of :198-203), SURVEY §8f N3.
+ * logits, gt: [B][n_per_image] f32 (n % 4 == 0); prediction = sigmoid(logit) > 0.5, target = int(gt) >= 1.
+ * counts [B][4] int64 = TP, FP, FN, TN per image; prob_sum [B] = sum of sigmoid(logit) over predicted-foreground pixels
+ * (numerator of the per-image mask score, :483).  Asynchronous, deterministic. */
+int64_t mtbt_seg_confusion_workspace_bytes(int B);
+int mtbt_seg_confusion(const float* logits, const float* gt, int B, int64_t n_per_image, int64_t* counts, float* prob_sum,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
 /* dtype / layout helpers on the boundary */
 int mtbt_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 

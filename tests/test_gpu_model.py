@@ -131,6 +131,50 @@ def test_postprocess_pipeline_on_model_outputs(pair):
         assert torch.allclose(d["boxes"][b].cpu(), boxes[b], rtol=1e-5, atol=1e-3)
 
 
+def test_validation_metrics_end_to_end(pair):
+    """SURVEY §8c acceptance metric: box mAP@0.5 / @0.5:0.95 and the projector-mask IoU / F1 of the whole HIP path (fp32 forward
+    -> decode -> NMS -> device metric accumulators) within 1e-3 of the all-CPU oracle path on a fixed synthetic det / GT set."""
+    from multitask_bonetumor_yolo_amd import MeanAveragePrecision, SegmentationMetrics
+    from oracle import metrics as om
+    ora, hip = pair
+    hip.set_compute_dtype(torch.float32)
+    B, S = 3, 160
+    g = torch.Generator().manual_seed(33)
+    x = torch.rand(B, 3, S, S, generator=g)
+    with torch.no_grad():
+        out = hip(x.to(DEV), "infer")
+        ref = ora(x, "infer")
+    _, mc, protos = out["segment_protos"]
+    res = pp.detect_and_segment(out["detect_features"], mc, protos, S, masks=False)
+    rboxes, rscores, _ = opp.decode_levels(ref["detect_features"], S)
+    preds_hip, preds_ora, targets = [], [], []
+    for b in range(B):
+        n = int(res["counts"][b])
+        preds_hip.append(dict(boxes=res["boxes"][b, :n], scores=res["scores"][b, :n], labels=res["labels"][b, :n]))
+        _, _, kb, ks, kl = opp.filter_and_nms(rboxes[b], rscores[b], S)
+        preds_ora.append(dict(boxes=kb, scores=ks, labels=kl))
+        pick = torch.arange(0, min(len(kb), 12), 3)                     # GT = every third of the oracle's best boxes, jittered
+        targets.append(dict(boxes=kb[pick] + torch.randn(len(pick), 4, generator=g) * 1.5, labels=kl[pick]))
+    assert sum(len(t["labels"]) for t in targets) > 0
+    for thr in ([0.5], torch.linspace(0.5, 0.95, 10).tolist()):          # running_main_v3.py:206-214
+        a, b_ = MeanAveragePrecision(thr, [1, 10, 100]), MeanAveragePrecision(thr, [1, 10, 100])
+        a.update(preds_hip, targets)
+        b_.update(preds_ora, targets)
+        ra, rb = a.compute(), b_.compute()
+        assert 0.0 < rb["map"] <= 1.0
+        for k in rb:
+            assert abs(ra[k] - rb[k]) <= 1e-3, (k, ra[k], rb[k])
+    # segmentation: projector logits (:251-255) -> pixel counts
+    w, bias = torch.randn(1, protos.shape[1], 1, 1, generator=g) * 0.5, torch.randn(1, generator=g) * 0.1
+    gt = (torch.rand(B, 1, S, S, generator=g) > 0.6).float()
+    sm = SegmentationMetrics()
+    sm.update(pp.proto_projector_logits(protos, w.to(DEV), bias.to(DEV), S), gt.to(DEV))
+    got = sm.compute()
+    rc, _ = om.seg_counts(opp.proto_projector_logits(ref["segment_protos"][2], w, bias, S), gt)
+    tp, fp, fn, tn = (float(v) for v in rc.sum(0))
+    assert abs(got["iou"] - tp / (tp + fp + fn)) <= 1e-3 and abs(got["f1"] - 2 * tp / (2 * tp + fp + fn)) <= 1e-3
+
+
 def test_train_mode_forward_batch_stat_heads():
     """forward(x, "train") under model.eval(): the reference flips the heads to train mode (main_model.py:358-359), so
     their BatchNorms use batch statistics and update the running statistics.  Fresh pair: state mutates."""
