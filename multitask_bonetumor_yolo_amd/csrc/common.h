@@ -104,6 +104,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// One-time (per kernel instantiation AND per device) opt-in to more than 64 KiB of dynamic LDS.  The flag array is racy
+// only in the benign direction (two host threads may both set the same attribute).
+template <typename K>
+static inline int mtbt_allow_lds(K kern, int lds) {
+  static bool done[64] = {};
+  if (lds <= 64 * 1024) return MTBT_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MTBT_ELAUNCH;
+  if (!done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MTBT_ELAUNCH;
+    done[dev] = true;
+  }
+  return MTBT_OK;
+}
+
 #define MTBT_LAUNCH_CHECK()                          \
   do {                                               \
     if (hipGetLastError() != hipSuccess) return MTBT_ELAUNCH; \

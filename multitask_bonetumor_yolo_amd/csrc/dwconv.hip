@@ -344,12 +344,7 @@ int launch_dw(const void* x, const void* w, const float* bias, const float* lnw,
   long blocks = tiles < resident ? tiles : resident;
   blocks = (blocks + 7) / 8 * 8;
   auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH, XB>;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    attr_set = true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return MTBT_ELAUNCH;
-  }
+  if (int rc = mtbt_allow_lds(kern, lds)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, (const T*)x, (const T*)w, bias, lnw, lnb, eps, scale, shift,
                      act, (T*)y, N, H, W, C, dbg_env());
   MTBT_LAUNCH_CHECK();

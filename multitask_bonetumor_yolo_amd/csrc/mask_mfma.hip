@@ -153,12 +153,7 @@ int mtbt_mask_x4_try(const mtbt_mask_args* a, hipStream_t stream) {
   p.tiles_x = a->Wout / 64;
   p.tiles_y = (a->Hout + 63) / 64;
   const size_t lds = (size_t)(NPXP * PPITCH + 16 * PPITCH + 16 * LPITCH) * sizeof(float);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    attr_set = true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_x4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return MTBT_ELAUNCH;
-  }
+  if (int rc = mtbt_allow_lds(mask_x4_kernel, (int)lds)) return rc;
   hipLaunchKernelGGL(mask_x4_kernel, dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;

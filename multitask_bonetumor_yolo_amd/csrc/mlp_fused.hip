@@ -221,12 +221,7 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   const long blocks = ((long)p.M + P - 1) / P;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    attr_set = true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<D, FP, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return MTBT_ELAUNCH;
-  }
+  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS>, lds)) return rc;
   hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
