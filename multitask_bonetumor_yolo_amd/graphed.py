@@ -26,7 +26,8 @@ class GraphedInference:
             for _ in range(warmup):           # first calls compile the plan and set one-time kernel attributes
                 self._step()
             torch.cuda.synchronize(x.device)
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            # thread_local: with a process group alive, RCCL's watchdog thread may touch the HIP runtime during the capture
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 self.fwd, self.out = self._step()
         torch.cuda.current_stream(x.device).wait_stream(self.stream)
 
