@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the device input pipeline (mtbt_letterbox_batch) on a batch of BTXRD-sized radiographs and the numpy oracle
-beside it.  usage: preprocess_bench.py [B] [H0] [W0] [S]"""
+beside it.  usage: python tests/bench_preprocess_vs_oracle.py [B] [H0] [W0] [S]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
