@@ -210,7 +210,7 @@ def main():
         conv_bytes = sum(l.bytes for l, _ in conv)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_direct_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_direct_kernel + conv3x3_rr_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv_bytes / len(conv)),
                     "launches_per_step": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),

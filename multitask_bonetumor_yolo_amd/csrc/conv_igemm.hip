@@ -113,7 +113,9 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
         a->W % 16 == 0 && a->out_mode == MTBT_OUT_NHWC && a->C % (128 / es) == 0 && a->K > 32 &&
         (long)a->H * a->W * a->x_pixel_stride * es < 0x7fff0000L && (long)128 * 9 * a->C * es < 0x7fff0000L) {
       int tc = (a->K >= 96 && !getenv("MTBT_DIRECT_TC64")) ? 128 : 64;
-      if ((pol & 8) || ((a->tile_hint >> 25) & 1)) tc |= 0x1000;  // row-reuse variant (conv3x3_rr_kernel): policy bit 3 / hint bit 25
+      // row-reuse variant (conv3x3_rr_kernel): the default for 64-channel tiles (head convs, 6 % faster there; policy bit 4
+      // turns that off), everywhere with policy bit 3 / hint bit 25
+      if ((pol & 8) || ((a->tile_hint >> 25) & 1) || (tc == 64 && !(pol & 16))) tc |= 0x1000;
       return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s);
     }
   }

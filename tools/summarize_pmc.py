@@ -12,7 +12,7 @@ def total(d, counter):
     n, s = 0, 0.0
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and ("conv_igemm_kernel" in r["Kernel_Name"] or "conv3x3_direct_kernel" in r["Kernel_Name"]):
+            if r["Counter_Name"] == counter and ("conv_igemm_kernel" in r["Kernel_Name"] or "conv3x3_direct_kernel" in r["Kernel_Name"] or "conv3x3_rr_kernel" in r["Kernel_Name"]):
                 n += 1
                 s += float(r["Counter_Value"])
     return n, s
