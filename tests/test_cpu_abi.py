@@ -46,6 +46,7 @@ def test_struct_layouts_match_header(tmp_path):
         "mtbt_decode_args": (L.DecodeArgs, ["map", "h", "map_pixel_stride", "stride", "n_levels", "xywh", "boxes", "preds_cat", "cat_stride"]),
         "mtbt_loss_args": (L.LossArgs, ["map", "h", "img_size", "gt_xyxy", "iou_thresh", "training", "seg_logits", "seg_bias", "seg_n", "img_gt",
                                         "n_img_classes", "w_img", "workspace", "workspace_bytes", "out"]),
+        "mtbt_raw_image": (L.RawImage, ["bgr", "mask", "height", "width", "row_stride", "mask_row_stride"]),
         "mtbt_mask_args": (L.MaskArgs, ["protos", "coeff_batch_stride", "gather_idx", "bias", "N", "Wout", "logits", "masks"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mtbt_hip.h"', 'int main(void){']
