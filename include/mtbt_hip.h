@@ -256,6 +256,16 @@ typedef struct mtbt_loss_args {
 int64_t mtbt_loss_workspace_bytes(int N, int A, int64_t seg_n);
 int mtbt_multitask_loss(const mtbt_loss_args* a, void* stream);
 
+/* Gradient of out[0] (the weighted total) with respect to the head outputs the loss reads -- what `total_loss.backward()` hands
+ * to the heads in `training_step` (running_main_v3.py:421-447), the first operator of the backward pass.  Call after
+ * mtbt_multitask_loss with the SAME args on the same stream (the batch's positive count is read from a->out[6]).
+ * d_map[l]: [N,h_l,w_l,4*reg_max+nc] f32 NHWC, pixel stride d_map_pixel_stride[l]; every element is written (zeros for anchors
+ * that are not positives).  d_seg_logits: seg_n floats (required when seg_n > 0) = w_seg / seg_n * (sigmoid - target);
+ * d_img_logits [N][n_img_classes] (may be NULL) = w_img / N * (softmax - onehot).  The positives mask, the matched GT index and
+ * the DFL targets carry no gradient, exactly as in autograd. */
+int mtbt_multitask_loss_grad(const mtbt_loss_args* a, float* const* d_map, const int32_t* d_map_pixel_stride, float* d_seg_logits,
+                             float* d_img_logits, void* stream);
+
 /* Fused ConvNeXt MLP (timm Mlp fc1 -> GELU -> fc2 with the layer-scale folded, + residual) for d in {96, 192}, bf16 only:
  *   y[p][:] = res[p][:] + W2' . GELU(W1 . t[p][:] + b1) + b2'      (the 4d-wide hidden tensor never leaves the chip)
  * t, res, y: dense [M][d] bf16; w1 [4d][d] bf16; b1 [4d] f32; b2 [d] f32; w2p [d][4d] bf16 whose columns are reordered

@@ -94,6 +94,7 @@ SYMBOLS = {
     "mtbt_mask_assemble": (C.c_int, [C.POINTER(MaskArgs), C.c_void_p]),
     "mtbt_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
     "mtbt_multitask_loss": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
+    "mtbt_multitask_loss_grad": (C.c_int, [C.POINTER(LossArgs), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtbt_convnext_mlp_fused": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mtbt_bbox_iou_pairwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mtbt_letterbox_batch": (C.c_int, [C.POINTER(RawImage), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),

@@ -1,7 +1,7 @@
 """Multitask loss value on the GPU: the reference's `MultiTaskLitModel._multitask_loss`
 (`/root/reference/src/running_main_v3.py:232-387`) as three kernel launches (csrc/loss.hip) instead of a per-image Python
-loop with `.item()` synchronisations.  Forward only: the returned 0-d tensors carry no autograd history (the backward
-pass is not built yet), so this serves validation / monitoring and the parity of the loss definition.
+loop with `.item()` synchronisations.  The returned 0-d tensors carry no autograd history; `with_grads=True` additionally
+returns the gradient of the total with respect to the head outputs (the rest of the backward pass is not built yet).
 
 No host synchronisation: the ground-truth boxes are grouped by image with device-side tensor ops, the positive count and
 the mean matched IoU come back as tensors (the reference returns Python floats, `:385`)."""
@@ -43,10 +43,12 @@ def group_gt_boxes(gt_boxes: torch.Tensor, n_images: int, img_size: float):
 def multitask_loss(det_maps: Sequence[torch.Tensor], protos: torch.Tensor, img_logits: torch.Tensor, gt_boxes: torch.Tensor,
                    gt_masks: torch.Tensor, gt_cls: torch.Tensor, proj_weight: torch.Tensor, proj_bias: torch.Tensor, *, img_size: int,
                    nc_det: int, reg_max: int = 16, iou_match_thresh: float = 0.5, label_smoothing: float = 0.0, training: bool = True,
-                   weights=(1.0, 2.0, 1.5, 0.5, 1.0)):
+                   weights=(1.0, 2.0, 1.5, 0.5, 1.0), with_grads: bool = False):
     """det_maps: the raw Detect maps of `forward(x, "train")` (3 x [B, 4*reg_max+nc, h, w]); protos [B, nm, hp, wp];
     gt_masks [B,1,S,S] float; gt_cls [B] int64; proj_*: the trainer's `seg_proto_projector` (`:186`).
-    Returns the reference's tuple as 0-d fp32 tensors: (total, seg, box, dfl, cls_det, img_cls[, n_pos, mean matched IoU])."""
+    Returns the reference's tuple as 0-d fp32 tensors: (total, seg, box, dfl, cls_det, img_cls[, n_pos, mean matched IoU]).
+    `with_grads=True` returns `(that tuple, grads)` where grads = d total / d {det_maps (list, like det_maps), seg_logits [B,1,S,S]
+    (the projector output after the bilinear resize, `:251-255`), img_logits}: the first operator of the backward pass."""
     lib = L.load()
     _need_cuda(det_maps[0], "multitask_loss")
     dev = det_maps[0].device
@@ -78,5 +80,19 @@ def multitask_loss(det_maps: Sequence[torch.Tensor], protos: torch.Tensor, img_l
     out = torch.empty(8, dtype=torch.float32, device=dev)
     a.workspace, a.workspace_bytes, a.out = ws.data_ptr(), nbytes, out.data_ptr()
     L.check(lib.mtbt_multitask_loss(C.byref(a), _stream(dev)), "mtbt_multitask_loss")
+    res = tuple(out[i] for i in range(8 if training else 6))
+    if not with_grads:
+        del keep
+        return res
+    # gradient of the total w.r.t. the head outputs (csrc/loss.hip: det_loss_grad_kernel, seg_img_grad_kernel)
+    no = 4 * reg_max + nc_det
+    d_maps = [torch.empty(m.shape[0], m.shape[2], m.shape[3], no, dtype=torch.float32, device=dev) for m in det_maps]
+    ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in d_maps], *([None] * (3 - len(d_maps))))
+    lds = (C.c_int32 * 3)(*([no] * len(d_maps)), *([0] * (3 - len(d_maps))))
+    d_seg = torch.empty_like(seg_logits)
+    d_img = torch.empty_like(il)
+    L.check(lib.mtbt_multitask_loss_grad(C.byref(a), ptrs, lds, d_seg.data_ptr(), d_img.data_ptr(), _stream(dev)), "mtbt_multitask_loss_grad")
     del keep
-    return tuple(out[i] for i in range(8 if training else 6))
+    grads = {"det_maps": [t.permute(0, 3, 1, 2) for t in d_maps],      # [B, no, h, w] views of channels-last memory
+             "seg_logits": d_seg.view(B, 1, img_size, img_size), "img_logits": d_img}
+    return res, grads

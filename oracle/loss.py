@@ -74,7 +74,7 @@ def multitask_loss(det_maps, protos, img_logits, gt_boxes, gt_masks, gt_cls, pro
         mgt = gxyxy[gi[pos]]
         miou = batch_bbox_iou(boxes[b][pos], mgt).diag()
         box_sum = box_sum + (1.0 - miou).sum()
-        iou_sum += float(miou.sum())
+        iou_sum += float(miou.detach().sum())
         mlog, mcls = cls_logits[b][pos], gcls[gi[pos]]
         if label_smoothing > 0.0 and training:
             tgt = torch.full_like(mlog, label_smoothing / (nc_det - 1))

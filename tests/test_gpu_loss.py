@@ -49,7 +49,7 @@ def test_gt_grouping_reproduces_reference_layout():
     assert torch.equal(xyxy.cpu(), torch.cat(ref_rows)) and torch.equal(cls.cpu(), torch.cat(ref_cls))
 
 
-def test_loss_against_oracle_at_model_scale():
+def _model_scale_case():
     """640 x 640, batch 4, 8400 anchors per image, several GT boxes per image, no positives in one image, nc = 3."""
     g = torch.Generator().manual_seed(17)
     B, S, NC = 4, 640, 3
@@ -83,6 +83,11 @@ def test_loss_against_oracle_at_model_scale():
     gcls = torch.tensor([0, 1, 1, 0])
     pw, pb = torch.randn(1, 32, 1, 1, generator=g) * 0.2, torch.tensor([0.1])
     kw = dict(img_size=S, nc_det=NC, label_smoothing=0.1, training=True)
+    return det, protos, logits, gt, masks, gcls, pw, pb, kw
+
+
+def test_loss_against_oracle_at_model_scale():
+    det, protos, logits, gt, masks, gcls, pw, pb, kw = _model_scale_case()
     ref = oracle_loss(det, protos, logits, gt, masks, gcls, pw, pb, **kw)
     out = multitask_loss([d.to(DEV) for d in det], protos.to(DEV), logits.to(DEV), gt.to(DEV), masks.to(DEV), gcls.to(DEV), pw.to(DEV),
                          pb.to(DEV), **kw)
@@ -99,3 +104,35 @@ def test_loss_against_oracle_at_model_scale():
     ref0 = oracle_loss(det, protos, logits, gt[:0], masks, gcls, pw, pb, **kw)
     for a, b in zip(out0, ref0):
         assert abs(float(a) - float(b)) <= 2e-4 * max(1.0, abs(float(b)))
+
+
+@pytest.mark.parametrize("with_gt", [True, False])
+def test_loss_gradients_match_autograd(with_gt):
+    """d total / d (det maps, seg logits, img logits) from the HIP kernels vs torch autograd through the oracle's restatement of
+    the reference loss (which the golden fixtures pin to MultiTaskLitModel._multitask_loss)."""
+    import torch.nn.functional as F
+    det, protos, logits, gt, masks, gcls, pw, pb, kw = _model_scale_case()
+    if not with_gt:
+        gt = gt[:0]
+    S = kw["img_size"]
+    det_r = [d.clone().requires_grad_() for d in det]
+    protos_r, logits_r = protos.clone().requires_grad_(), logits.clone().requires_grad_()
+    ref = oracle_loss(det_r, protos_r, logits_r, gt, masks, gcls, pw, pb, **kw)
+    ref[0].backward()
+    out, grads = multitask_loss([d.to(DEV) for d in det], protos.to(DEV), logits.to(DEV), gt.to(DEV), masks.to(DEV), gcls.to(DEV), pw.to(DEV),
+                                pb.to(DEV), with_grads=True, **kw)
+    assert abs(float(out[0]) - float(ref[0])) <= 2e-4 * max(1.0, abs(float(ref[0])))
+    n_nonzero = 0
+    for a, r in zip(grads["det_maps"], det_r):
+        want = r.grad if r.grad is not None else torch.zeros_like(r)
+        assert a.shape == want.shape
+        got = a.cpu()
+        assert (got - want).abs().max().item() <= 1e-6 + 1e-4 * want.abs().max().item()
+        assert torch.equal(got == 0, want == 0) or (got - want).abs().max().item() < 1e-7   # same anchors carry gradient
+        n_nonzero += int((want != 0).sum())
+    assert (n_nonzero > 1000) == with_gt
+    assert torch.allclose(grads["img_logits"].cpu(), logits_r.grad, rtol=1e-4, atol=1e-7)
+    # seg logits -> protos through the projector + bilinear resize (their backward is torch's here): must equal autograd's d protos
+    p2 = protos.clone().requires_grad_()
+    F.interpolate(F.conv2d(p2, pw, pb), size=(S, S), mode="bilinear", align_corners=False).backward(grads["seg_logits"].cpu())
+    assert torch.allclose(p2.grad, protos_r.grad, rtol=1e-4, atol=1e-10)
