@@ -1,0 +1,51 @@
+"""Input gradients (dgrad) of the network's convolutions through the FORWARD kernels -- the first building block of the
+backward pass.  No new GEMM kernel is needed for any of them:
+
+  k x k, stride 1   dX = conv(dY, W'), W'[c][r][s][k] = W[k][R-1-r][S-1-s][c], padding R-1-pad     (mtbt_conv2d_nhwc)
+  1 x 1 / Linear     the transposed weight (the case R = S = 1 of the line above)
+  2 x 2, stride 2    dX = conv_transpose(dY, W): the OUT_CONVT2X2 scatter mode of the same kernel   (ConvNeXt downsample)
+  depthwise k x k    the depthwise kernel on dY with the taps flipped                                (mtbt_dwconv_nhwc)
+
+These are the linear parts only: the activation derivative on the way in, weight gradients, normalisation backward and the
+optimiser are not built yet.  Everything here appends launches to an `engine.Plan`; weights are re-laid out once by the
+`*_weight` helpers (device tensors, any dtype the kernels take)."""
+import torch
+
+from . import _lib as L
+from .engine import Act, Plan
+
+
+def dgrad_weight(w_packed: torch.Tensor, R: int, S: int) -> torch.Tensor:
+    """Forward weight packed [K, R*S*C] (as `Plan.conv` takes it) -> dgrad weight packed [C, R*S*K]."""
+    K = w_packed.shape[0]
+    C = w_packed.shape[1] // (R * S)
+    return w_packed.view(K, R, S, C).flip(1, 2).permute(3, 1, 2, 0).reshape(C, R * S * K).contiguous()
+
+
+def conv_dgrad(plan: Plan, dy: Act, w_dgrad: torch.Tensor, dx: Act, *, R: int, S: int, pad: int, name="conv.dgrad"):
+    """Stride-1 convolution: dx [N,H,W,C] from dy [N,H,W,K] (same spatial size, i.e. 2*pad == R-1 == S-1, or R = S = 1)."""
+    assert R == S and 2 * pad == R - 1, "stride-1 'same' convolutions only"
+    return plan.conv(dy, w_dgrad, dx, R=R, S=S, stride=1, pad=R - 1 - pad, name=name)
+
+
+def downsample2x2_dgrad_weight(w_packed: torch.Tensor) -> torch.Tensor:
+    """Forward weight of a 2x2 / stride-2 conv packed [K, 2*2*C] -> the [4*C, K] layout of the OUT_CONVT2X2 mode."""
+    K = w_packed.shape[0]
+    C = w_packed.shape[1] // 4
+    return w_packed.view(K, 2, 2, C).permute(1, 2, 3, 0).reshape(4 * C, K).contiguous()
+
+
+def downsample2x2_dgrad(plan: Plan, dy: Act, w_t: torch.Tensor, dx: Act, name="downsample.dgrad"):
+    """dx [N,2H,2W,C] from dy [N,H,W,K]: every output pixel receives exactly one tap (non-overlapping patches)."""
+    return plan.conv(dy, w_t, dx, out_mode=L.OUT_CONVT2X2, name=name)
+
+
+def dwconv_dgrad_weight(w_taps: torch.Tensor, ksize: int) -> torch.Tensor:
+    """Depthwise taps [k*k, C] -> flipped taps."""
+    return w_taps.view(ksize, ksize, -1).flip(0, 1).reshape(ksize * ksize, -1).contiguous()
+
+
+def dwconv_dgrad(plan: Plan, dy: Act, w_flipped: torch.Tensor, dx: Act, ksize: int, ones: torch.Tensor, zeros: torch.Tensor,
+                 name="dwconv.dgrad"):
+    """Depthwise stride-1 'same' convolution; `ones` / `zeros`: fp32 [C] (identity epilogue of the depthwise kernel)."""
+    return plan.dwconv(dy, w_flipped, dx, ksize, scale=ones, shift=zeros, name=name)

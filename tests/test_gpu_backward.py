@@ -1,0 +1,83 @@
+"""Input gradients of the convolutions through the forward kernels (multitask_bonetumor_yolo_amd/backward.py) vs torch autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+if torch.cuda.is_available():
+    from multitask_bonetumor_yolo_amd import backward as B
+    from multitask_bonetumor_yolo_amd.engine import Act, Plan
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def run(p):
+    p.run(stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
+def check(got_nhwc, want_nchw, dtype):
+    got = got_nhwc.float().cpu().permute(0, 3, 1, 2)
+    if dtype == torch.float32:
+        assert (got - want_nchw).abs().max().item() < 2e-4
+    else:
+        assert ((got - want_nchw).abs() / (want_nchw.abs() + 1.0)).max().item() < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,C,K,k", [(2, 16, 32, 64, 128, 3), (1, 20, 20, 128, 64, 3), (2, 9, 7, 96, 384, 1), (1, 12, 12, 384, 96, 1)])
+def test_conv_dgrad(dtype, N, H, W, C, K, k):
+    g = torch.Generator().manual_seed(N * H + K)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(K, C, k, k, generator=g) / (C * k * k) ** 0.5
+    dy = torch.randn(N, K, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        w, dy = w.bfloat16().float(), dy.bfloat16().float()
+    (want,) = torch.autograd.grad(F.conv2d(x, w, None, 1, k // 2), x, dy)
+    wp = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().to(DEV, dtype)              # the forward layout [K, R*S*C]
+    p = Plan(torch.device(DEV))
+    dx = Act.of(torch.zeros(N, H, W, C, dtype=dtype, device=DEV))
+    B.conv_dgrad(p, Act.of(nhwc(dy).to(dtype)), B.dgrad_weight(wp, k, k), dx, R=k, S=k, pad=k // 2)
+    run(p)
+    check(dx.buf, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_downsample_dgrad(dtype):
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C, K = 2, 12, 8, 96, 192
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(K, C, 2, 2, generator=g) / (4 * C) ** 0.5
+    dy = torch.randn(N, K, H // 2, W // 2, generator=g)
+    if dtype == torch.bfloat16:
+        w, dy = w.bfloat16().float(), dy.bfloat16().float()
+    (want,) = torch.autograd.grad(F.conv2d(x, w, None, 2, 0), x, dy)
+    wp = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().to(DEV, dtype)
+    p = Plan(torch.device(DEV))
+    dx = Act.of(torch.zeros(N, H, W, C, dtype=dtype, device=DEV))
+    B.downsample2x2_dgrad(p, Act.of(nhwc(dy).to(dtype)), B.downsample2x2_dgrad_weight(wp), dx)
+    run(p)
+    check(dx.buf, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,k,H", [(96, 7, 24), (256, 3, 20), (384, 7, 12)])
+def test_dwconv_dgrad(dtype, C, k, H):
+    g = torch.Generator().manual_seed(C + k)
+    N = 2
+    x = torch.randn(N, C, H, H, generator=g, requires_grad=True)
+    w = torch.randn(C, 1, k, k, generator=g) / k
+    dy = torch.randn(N, C, H, H, generator=g)
+    if dtype == torch.bfloat16:
+        w, dy = w.bfloat16().float(), dy.bfloat16().float()
+    (want,) = torch.autograd.grad(F.conv2d(x, w, None, 1, k // 2, groups=C), x, dy)
+    taps = w.view(C, k * k).t().contiguous().to(DEV, dtype)                              # the forward layout [k*k, C]
+    p = Plan(torch.device(DEV))
+    dx = Act.of(torch.zeros(N, H, H, C, dtype=dtype, device=DEV))
+    B.dwconv_dgrad(p, Act.of(nhwc(dy).to(dtype)), B.dwconv_dgrad_weight(taps, k), dx, k, torch.ones(C, device=DEV), torch.zeros(C, device=DEV))
+    run(p)
+    check(dx.buf, want, dtype)
