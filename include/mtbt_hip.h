@@ -304,6 +304,12 @@ int64_t mtbt_seg_confusion_workspace_bytes(int B);
 int mtbt_seg_confusion(const float* logits, const float* gt, int B, int64_t n_per_image, int64_t* counts, float* prob_sum,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
+ * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
+ * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */
+int mtbt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 /* dtype / layout helpers on the boundary */
 int mtbt_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 
