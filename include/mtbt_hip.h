@@ -304,6 +304,16 @@ int64_t mtbt_seg_confusion_workspace_bytes(int B);
 int mtbt_seg_confusion(const float* logits, const float* gt, int B, int64_t n_per_image, int64_t* counts, float* prob_sum,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Weight gradient of a stride-1 "same" k x k convolution (2 * pad == R - 1 == S - 1; R = S = 1 included), bf16 operands:
+ *   dw[k][r][s][c] (fp32, packed [K][R*S*C] like the forward weight) (+)= sum_p dy[p][k] * x[p shifted by (r - pad, s - pad)][c]
+ * x [N,H,W,C], dy [N,H,W,K] NHWC with pixel / batch strides in elements (multiples of 8; C % 8 == K % 8 == 0).  accumulate != 0
+ * adds to dw (gradient accumulation into a flat bucket).  Deterministic: per-slice fp32 partials in `workspace`
+ * (>= mtbt_conv_wgrad_workspace_bytes) summed in a fixed order.  This is what autograd computes for `Conv2d.weight.grad`. */
+int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S);
+int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad,
+                    int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
+                    int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
  * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */

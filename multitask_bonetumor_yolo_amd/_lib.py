@@ -100,6 +100,9 @@ SYMBOLS = {
     "mtbt_letterbox_batch": (C.c_int, [C.POINTER(RawImage), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "mtbt_seg_confusion_workspace_bytes": (C.c_int64, [C.c_int]),
     "mtbt_seg_confusion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 7),
+    "mtbt_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 8 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_int64, C.c_void_p]),
     "mtbt_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -81,3 +81,23 @@ def test_dwconv_dgrad(dtype, C, k, H):
     B.dwconv_dgrad(p, Act.of(nhwc(dy).to(dtype)), B.dwconv_dgrad_weight(taps, k), dx, k, torch.ones(C, device=DEV), torch.zeros(C, device=DEV))
     run(p)
     check(dx.buf, want, dtype)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,k", [(2, 16, 16, 64, 64, 3), (1, 20, 20, 128, 96, 3), (2, 9, 7, 96, 384, 1), (3, 40, 40, 256, 64, 3), (1, 5, 3, 8, 8, 3)])
+def test_conv_wgrad(N, H, W, C, K, k):
+    """Weight gradient (csrc/wgrad.hip) vs autograd, bf16-rounded operands, ragged channel tiles and pixel slices."""
+    g = torch.Generator().manual_seed(N * H + K + k)
+    x = (torch.randn(N, C, H, W, generator=g)).bfloat16().float()
+    w = (torch.randn(K, C, k, k, generator=g) / (C * k * k) ** 0.5).requires_grad_()
+    dy = torch.randn(N, K, H, W, generator=g).bfloat16().float()
+    (want,) = torch.autograd.grad(F.conv2d(x, w, None, 1, k // 2), w, dy)
+    want = want.permute(0, 2, 3, 1).reshape(K, -1)                                   # packed [K, R*S*C]
+    xa, dya = Act.of(nhwc(x).bfloat16()), Act.of(nhwc(dy).bfloat16())
+    got = B.conv_wgrad(xa, dya, R=k, S=k, pad=k // 2)
+    torch.cuda.synchronize()
+    scale = want.abs().max().item()
+    assert (got.cpu() - want).abs().max().item() <= 2e-4 * scale + 1e-5               # fp32 accumulation of exact bf16 products
+    again = B.conv_wgrad(xa, dya, R=k, S=k, pad=k // 2)
+    assert torch.equal(got, again)                                                    # deterministic
+    acc = B.conv_wgrad(xa, dya, R=k, S=k, pad=k // 2, out=got.clone(), accumulate=True)
+    assert torch.allclose(acc, 2 * got, rtol=1e-5, atol=1e-5 * scale)                # (dw + partials) rounds differently from 2 * dw
