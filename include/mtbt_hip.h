@@ -314,6 +314,15 @@ int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int 
                     int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Pointwise pieces of the backward pass.  mtbt_act_backward: dz[i] = dy[i] * act'(z[i]) for MTBT_ACT_* (z = the PRE-activation the
+ * training forward keeps; n % 8 == 0; dtype f32 or bf16 for all three arrays).  mtbt_channel_sum: out[c] (+)= sum_p x[p][c] (* x2[p][c]
+ * when x2 != NULL) over `pixels` rows of pixel_stride elements (C % 8 == 0): the gradient of a conv bias / BatchNorm shift, and
+ * with x2 of a BatchNorm scale / layer-scale; deterministic. */
+int mtbt_act_backward(const void* dy, const void* z, void* dz, int64_t n, int act, int dtype, void* stream);
+int64_t mtbt_channel_sum_workspace_bytes(int64_t pixels, int C);
+int mtbt_channel_sum(const void* x, const void* x2, int64_t pixels, int C, int32_t pixel_stride, int32_t pixel_stride2, int dtype,
+                     float* out, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
  * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */

@@ -103,6 +103,10 @@ SYMBOLS = {
     "mtbt_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 7),
     "mtbt_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 8 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
+    "mtbt_act_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_channel_sum_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "mtbt_channel_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_int64, C.c_void_p]),
     "mtbt_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -71,3 +71,34 @@ def conv_wgrad(x: Act, dy: Act, *, R: int, S: int, pad: int, out: torch.Tensor =
                                 x.code, int(accumulate), ws.data_ptr(), nbytes, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
             "mtbt_conv_wgrad")
     return out
+
+
+def act_backward(dy: Act, z: Act, act: int, out: Act = None) -> Act:
+    """dz = dy * act'(z) (z = pre-activation), dense NHWC tensors of one dtype.  Runs on the current stream."""
+    import ctypes as C
+    lib = L.load()
+    assert dy.dense and z.dense and dy.code == z.code and dy.buf.shape == z.buf.shape
+    if out is None:
+        out = Act.of(torch.empty_like(dy.buf))
+    dev = dy.buf.device
+    L.check(lib.mtbt_act_backward(dy.ptr, z.ptr, out.ptr, dy.buf.numel(), act, dy.code, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            "mtbt_act_backward")
+    return out
+
+
+def channel_sum(x: Act, out: torch.Tensor = None, accumulate: bool = False, times: Act = None) -> torch.Tensor:
+    """fp32 [C] = sum over all pixels of x [N,H,W,C] (bias / shift gradient), or of x * times (scale gradient).  `out` may be a view
+    into a gradient bucket."""
+    import ctypes as C
+    lib = L.load()
+    assert x.dense and (times is None or (times.dense and times.code == x.code and times.C == x.C))
+    dev = x.buf.device
+    P = x.N * x.H * x.W
+    if out is None:
+        out = torch.empty(x.C, dtype=torch.float32, device=dev)
+    nbytes = lib.mtbt_channel_sum_workspace_bytes(P, x.C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    L.check(lib.mtbt_channel_sum(x.ptr, times.ptr if times is not None else None, P, x.C, x.ld, times.ld if times is not None else 0, x.code,
+                                 out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes,
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_channel_sum")
+    return out

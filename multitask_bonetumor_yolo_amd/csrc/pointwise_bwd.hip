@@ -1,0 +1,113 @@
+// Pointwise pieces of the backward pass, HBM-bound:
+//   mtbt_act_backward   dz = dy * act'(z) for the activations of the forward epilogues (SiLU: ConvBlock / ultralytics Conv,
+//                       main_model.py:136; ELU: DepthwiseConvBlock, :96; GELU erf form: timm Mlp) -- z is the PRE-activation,
+//                       which a training forward keeps (bf16) next to the activated output
+//   mtbt_channel_sum    out[c] (+)= sum over pixels of dz[p][c] (* u[p][c] if a second operand is given): the gradient of a conv
+//                       bias / BatchNorm shift, and of a BatchNorm scale / layer-scale (product with the normalised input); two fixed-order levels (per-workgroup partial rows in the workspace, then one pass), deterministic
+// fp32 arithmetic with libm exp / erf; 16-byte accesses.
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == MTBT_ACT_SILU) { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
+  if (act == MTBT_ACT_ELU) return z > 0.f ? 1.f : expf(z);
+  if (act == MTBT_ACT_GELU || act == MTBT_ACT_GELU_POLY)
+    return 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+  return 1.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_backward_kernel(const T* __restrict__ dy, const T* __restrict__ z, T* __restrict__ dz, long n8, int act) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float a[8], b[8];
+    ld8(dy + i * 8, a);
+    ld8(z + i * 8, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] *= act_grad(b[k], act);
+    st8(dz + i * 8, a);
+  }
+}
+
+constexpr int ROWS_PER_BLOCK = 256;   // pixels per workgroup in the first level
+
+// lane group = 8 channels (one 16-byte chunk); a workgroup sums ROWS_PER_BLOCK pixels of every chunk it is given
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__ x, const T* __restrict__ x2, long P, int C, int ld, int ld2,
+                                                           float* __restrict__ partial) {
+  const int chunks = C >> 3;
+  const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK, p1 = min(P, p0 + ROWS_PER_BLOCK);
+  for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long p = p0; p < p1; ++p) {
+      float v[8];
+      ld8(x + p * ld + ch * 8, v);
+      if (x2) {
+        float u[8];
+        ld8(x2 + p * ld2 + ch * 8, u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= u[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * C + ch * 8 + k] = s[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_sum_final(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int b = 0; b < blocks; ++b) s += partial[(long)b * C + c];
+  out[c] = s;
+}
+
+}  // namespace
+
+extern "C" int mtbt_act_backward(const void* dy, const void* z, void* dz, int64_t n, int act, int dtype, void* stream) {
+  if (!dy || !z || !dz || n < 0 || n % 8 || act < MTBT_ACT_NONE || act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
+  if (!aligned16(dy) || !aligned16(z) || !aligned16(dz)) return MTBT_EALIGN;
+  if (n == 0) return MTBT_OK;
+  const long n8 = n / 8;
+  long blocks = (n8 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MTBT_BF16)
+    hipLaunchKernelGGL(act_backward_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)z, (bf16_t*)dz, n8, act);
+  else if (dtype == MTBT_F32)
+    hipLaunchKernelGGL(act_backward_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)z, (float*)dz, n8, act);
+  else
+    return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int64_t mtbt_channel_sum_workspace_bytes(int64_t pixels, int C) {
+  if (pixels <= 0 || C <= 0) return 0;
+  return ((pixels + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * (int64_t)C * (int64_t)sizeof(float);
+}
+
+extern "C" int mtbt_channel_sum(const void* x, const void* x2, int64_t pixels, int C, int32_t pixel_stride, int32_t pixel_stride2, int dtype,
+                                float* out, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !out || !workspace || pixels <= 0 || C <= 0 || C % 8 || pixel_stride < C || pixel_stride % 8) return MTBT_EINVAL;
+  if (x2 && (pixel_stride2 < C || pixel_stride2 % 8)) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(workspace) || (x2 && !aligned16(x2))) return MTBT_EALIGN;
+  if (workspace_bytes < mtbt_channel_sum_workspace_bytes(pixels, C)) return MTBT_EWORKSPACE;
+  const long blocks = (pixels + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (dtype == MTBT_BF16)
+    hipLaunchKernelGGL(channel_sum_partial<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)x2, (long)pixels, C, pixel_stride, pixel_stride2, partial);
+  else if (dtype == MTBT_F32)
+    hipLaunchKernelGGL(channel_sum_partial<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, (const float*)x2, (long)pixels, C, pixel_stride, pixel_stride2, partial);
+  else
+    return MTBT_EINVAL;
+  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, (int)blocks, C, out, accumulate);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}

@@ -101,3 +101,83 @@ def test_conv_wgrad(N, H, W, C, K, k):
     assert torch.equal(got, again)                                                    # deterministic
     acc = B.conv_wgrad(xa, dya, R=k, S=k, pad=k // 2, out=got.clone(), accumulate=True)
     assert torch.allclose(acc, 2 * got, rtol=1e-5, atol=1e-5 * scale)                # (dw + partials) rounds differently from 2 * dw
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["silu", "elu", "gelu", "none"])
+def test_act_backward(dtype, act):
+    from multitask_bonetumor_yolo_amd import _lib as L
+    code = {"silu": L.ACT_SILU, "elu": L.ACT_ELU, "gelu": L.ACT_GELU, "none": L.ACT_NONE}[act]
+    fn = {"silu": F.silu, "elu": F.elu, "gelu": F.gelu, "none": lambda t: t}[act]
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randn(2, 24, 9, 11, generator=g) * 3).to(dtype).float().requires_grad_()
+    dy = torch.randn(2, 24, 9, 11, generator=g).to(dtype).float()
+    (want,) = torch.autograd.grad(fn(z), z, dy)
+    got = B.act_backward(Act.of(nhwc(dy).to(dtype)), Act.of(nhwc(z.detach()).to(dtype)), code)
+    torch.cuda.synchronize()
+    check(got.buf, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_channel_sum(dtype):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 40, 31, 23, generator=g).to(dtype).float()          # 2139 pixels: ragged last workgroup
+    a = Act.of(nhwc(x).to(dtype))
+    got = B.channel_sum(a)
+    torch.cuda.synchronize()
+    want = x.sum(dim=(0, 2, 3))
+    assert torch.allclose(got.cpu(), want, rtol=1e-5, atol=1e-3)
+    assert torch.equal(got, B.channel_sum(a))
+    twice = B.channel_sum(a, out=got.clone(), accumulate=True)
+    assert torch.allclose(twice.cpu(), 2 * want, rtol=1e-5, atol=2e-3)
+    y = torch.randn(3, 40, 31, 23, generator=g).to(dtype).float()
+    dot = B.channel_sum(a, times=Act.of(nhwc(y).to(dtype)))
+    assert torch.allclose(dot.cpu(), (x * y).sum(dim=(0, 2, 3)), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("k", [3, 1])
+def test_convblock_backward_composes(k):
+    """Backward of one reference-owned block -- ConvBlock = Conv2d(bias) -> BatchNorm2d (running statistics) -> SiLU,
+    main_model.py:113-141 -- assembled from the pieces (activation derivative, channel sums, dgrad through the forward kernel,
+    wgrad) against torch autograd through the oracle block: dx, dW, d bias, d gamma, d beta.  bf16 activations, fp32 gradients."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    from oracle.blocks import ConvBlock
+    torch.manual_seed(11)
+    N, H, W, C, K = 2, 20, 20, 64, 128
+    blk = ConvBlock(C, K, k).eval()
+    with torch.no_grad():
+        blk.bn.running_mean.normal_(0, 0.1); blk.bn.running_var.uniform_(0.5, 1.5)
+        blk.bn.weight.uniform_(0.5, 1.5); blk.bn.bias.normal_(0, 0.1)
+        blk.conv.weight.copy_(blk.conv.weight.bfloat16().float())
+    x = torch.randn(N, C, H, W).bfloat16().float().requires_grad_()
+    dy = torch.randn(N, K, H, W).bfloat16().float()
+    blk(x).backward(dy)
+    # ---- the same with the HIP pieces ----
+    s = (blk.bn.weight / torch.sqrt(blk.bn.running_var + blk.bn.eps)).detach()           # u = s * (W*x + b) + t
+    t = (blk.bn.bias - blk.bn.running_mean * s).detach()
+    wp = blk.conv.weight.detach().permute(0, 2, 3, 1).reshape(K, -1).contiguous()          # [K, R*S*C]
+    p = Plan(torch.device(DEV))
+    xa = Act.of(nhwc(x.detach()).bfloat16())
+    u = Act.of(torch.empty(N, H, W, K, dtype=torch.bfloat16, device=DEV))                 # pre-activation kept by a training forward
+    p.conv(xa, wp.to(DEV, torch.bfloat16), u, R=k, S=k, pad=k // 2, scale=s.to(DEV), shift=(blk.conv.bias.detach() * s + t).to(DEV))
+    run(p)
+    du = B.act_backward(Act.of(nhwc(dy).bfloat16()), u, L.ACT_SILU)                        # dy * SiLU'(u)
+    d_beta = B.channel_sum(du)
+    d_udotu = B.channel_sum(du, times=u)
+    sd, td = s.to(DEV), t.to(DEV)
+    gamma, beta = blk.bn.weight.detach().to(DEV), blk.bn.bias.detach().to(DEV)
+    d_gamma = (d_udotu - beta * d_beta) / gamma                                            # sum du * (u - beta) / gamma
+    d_bias = d_beta * sd                                                                   # d(W*x + b) = s * du
+    dW = B.conv_wgrad(xa, du, R=k, S=k, pad=k // 2) * sd[:, None]
+    p2 = Plan(torch.device(DEV))
+    dx = Act.of(torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV))
+    B.conv_dgrad(p2, du, B.dgrad_weight((wp.to(DEV) * sd[:, None]).to(torch.bfloat16), k, k), dx, R=k, S=k, pad=k // 2)
+    run(p2)
+
+    def close(got, want, tol):
+        return (got.float().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
+    assert close(dx.buf.permute(0, 3, 1, 2), x.grad, 3e-2)                                 # bf16 du, bf16 folded weights, bf16 dx
+    assert close(dW, blk.conv.weight.grad.permute(0, 2, 3, 1).reshape(K, -1), 2e-2)
+    assert close(d_bias, blk.conv.bias.grad, 2e-2)
+    assert close(d_beta, blk.bn.bias.grad, 2e-2)
+    assert close(d_gamma, blk.bn.weight.grad, 3e-2)
