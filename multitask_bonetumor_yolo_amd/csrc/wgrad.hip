@@ -5,12 +5,13 @@
 // 16-lane group, which is exactly one half of a 16x16x32 operand fragment, so the tiles are staged in their natural layout
 // ([pixel][channel] rows, 16-byte global loads) and transposed by the read.
 //
-//   workgroup   one (64 output channels) x (64 input channels) tile of one filter tap, over one slice of the pixel range;
-//               wave w owns output channels 16 w .. 16 w + 15 and all 64 input channels (4 accumulator fragments)
-//   step        32 pixels: dY tile [32][64] and the tap-shifted X tile [32][64] (zeros outside the image) through registers
-//               into LDS, two transposed reads per operand fragment, 4 MFMAs per wave
+//   workgroup   one (128 output channels) x (128 input channels) tile of one filter tap, over one slice of the pixel range;
+//               waves 2 x 2, each 64 x 64 channels (16 accumulator fragments)
+//   step        64 pixels: dY tile [64][128] and the tap-shifted X tile [64][128] (zeros outside the image) through registers
+//               into LDS (32-byte units XOR-permuted so that the transposed reads are conflict-free), per 32 pixels 16
+//               transposed reads and 16 MFMAs per wave
 //   reduction   fp32 partial tiles per pixel slice, summed in slice order by a second kernel (deterministic; no atomics)
-// First correct version: single-buffered, unswizzled LDS rows.  Its place in the plan and what comes next: DESIGN.md §7.
+// Register double-buffering: the global loads of step t+1 are issued before the MFMAs of step t; one LDS buffer.  Its place in the plan and what comes next: DESIGN.md §7.
 #include "common.h"
 
 namespace {
@@ -18,7 +19,7 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int TK = 64, TCH = 64, TPX = 32;
+constexpr int TK = 128, TCH = 128, TPX = 64, LPT = TPX / 16;   // LPT: 16-byte loads per thread and tile in one step
 
 struct WgP {
   const bf16_t* x; const bf16_t* dy; float* partial;
@@ -32,6 +33,14 @@ __device__ __forceinline__ s16x4 tr_read(const bf16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+// LDS image of a [pixel][128 channels] tile: 256-byte rows, the eight 32-byte units of a row XOR-permuted by
+// (row & 3) | ((row >> 3) & 1) << 2.  One transposed read of a 32-lane half touches rows r0 .. r0+3 and r0+8 .. r0+11 of one
+// unit column: with the permutation their eight 32-byte windows cover all 64 banks exactly once.
+__device__ __forceinline__ int swz_unit(int row, int unit) { return unit ^ ((row & 3) | (((row >> 3) & 1) << 2)); }
+__device__ __forceinline__ int tile_off(int row, int col) {   // element offset of (row, col); col % 4 == 0 stays inside its unit
+  return row * 128 + (swz_unit(row, col >> 4) << 4) + (col & 15);
+}
+
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
   __shared__ __attribute__((aligned(16))) bf16_t sdy[TPX * TK];
   __shared__ __attribute__((aligned(16))) bf16_t sx[TPX * TCH];
@@ -43,54 +52,77 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
   const int split = b / taps;
   const int r = tap / p.S, s = tap - r * p.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = tid >> 3, chunk = tid & 7;       // staging: tile row (pixel of the step), 16-byte chunk (8 channels)
+  const int wk = wave & 1, wc = wave >> 1;            // wave tile: 64 output channels x 64 input channels
+  const int row = tid >> 4, chunk = tid & 15;         // staging: tile row (pixel of the pass), 16-byte chunk (8 channels)
   const int HW = p.H * p.W;
   const long p0 = (long)split * p.per, p1 = min(p.P, p0 + p.per);
   const int kch = kt * TK + chunk * 8, cch = ct * TCH + chunk * 8;
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const bf16_t* a_lo = sdy + (8 * g + q) * TK + 16 * wave + 4 * pp;      // rows 8g .. 8g+3 of the step (operand k index)
-  const bf16_t* b_lo = sx + (8 * g + q) * TCH + 4 * pp;
 
-  f32x4 acc[4];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (long pb = p0; pb < p1; pb += TPX) {
-    const long pix = pb + row;
-    uint4 vdy = {0u, 0u, 0u, 0u}, vx = {0u, 0u, 0u, 0u};
-    if (pix < p1) {
-      const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
-      const int y = rem / p.W, xx = rem - y * p.W;
-      if (kch < p.K) vdy = *reinterpret_cast<const uint4*>(p.dy + (long)n * p.dy_bs + (long)rem * p.ldy + kch);
-      const int iy = y + r - p.pad, ix = xx + s - p.pad;
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cch < p.C)
-        vx = *reinterpret_cast<const uint4*>(p.x + (long)n * p.x_bs + ((long)iy * p.W + ix) * p.ldx + cch);
+  uint4 vdy[LPT], vx[LPT];
+  auto fetch = [&](long pb) {   // this thread's 16-byte pieces of the step starting at pixel pb (zeros past the slice / outside the image)
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const long pix = pb + i * 16 + row;
+      vdy[i] = vx[i] = uint4{0u, 0u, 0u, 0u};
+      if (pix < p1) {
+        const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
+        const int y = rem / p.W, xx = rem - y * p.W;
+        if (kch < p.K) vdy[i] = *reinterpret_cast<const uint4*>(p.dy + (long)n * p.dy_bs + (long)rem * p.ldy + kch);
+        const int iy = y + r - p.pad, ix = xx + s - p.pad;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cch < p.C)
+          vx[i] = *reinterpret_cast<const uint4*>(p.x + (long)n * p.x_bs + ((long)iy * p.W + ix) * p.ldx + cch);
+      }
     }
+  };
+  if (p0 < p1) fetch(p0);
+  for (long pb = p0; pb < p1; pb += TPX) {
     __syncthreads();                                   // the previous step's fragment reads are done
-    *reinterpret_cast<uint4*>(sdy + row * TK + chunk * 8) = vdy;
-    *reinterpret_cast<uint4*>(sx + row * TCH + chunk * 8) = vx;
-    __syncthreads();
-    // every lane takes part in the transposed reads (EXEC must be full): no divergence from here to the MFMAs
-    const s16x4 a0 = tr_read(a_lo), a1 = tr_read(a_lo + 4 * TK);
-    const s16x8 A = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const s16x4 b0 = tr_read(b_lo + 16 * f), b1 = tr_read(b_lo + 16 * f + 4 * TCH);
-      const s16x8 B = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc[f], 0, 0, 0);
+    for (int i = 0; i < LPT; ++i) {
+      const int tr = i * 16 + row;
+      *reinterpret_cast<uint4*>(sdy + tile_off(tr, chunk * 8)) = vdy[i];
+      *reinterpret_cast<uint4*>(sx + tile_off(tr, chunk * 8)) = vx[i];
+    }
+    __syncthreads();
+    if (pb + TPX < p1) fetch(pb + TPX);                // the next step's global loads are in flight during this step's MFMAs
+    // every lane takes part in the transposed reads (EXEC must be full): the branches above are uniform or closed by now
+#pragma unroll
+    for (int i = 0; i < TPX / 32; ++i) {
+      const int r_lo = i * 32 + 8 * g + q, r_hi = r_lo + 4;     // operand k index 8g .. 8g+3 and 8g+4 .. 8g+7 of this 32-pixel group
+      s16x8 A[4], B[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int ca = 64 * wk + 16 * f + 4 * pp, cb = 64 * wc + 16 * f + 4 * pp;
+        A[f] = __builtin_shufflevector(tr_read(sdy + tile_off(r_lo, ca)), tr_read(sdy + tile_off(r_hi, ca)), 0, 1, 2, 3, 4, 5, 6, 7);
+        B[f] = __builtin_shufflevector(tr_read(sx + tile_off(r_lo, cb)), tr_read(sx + tile_off(r_hi, cb)), 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int fa = 0; fa < 4; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+          acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, B[fb]), acc[fa][fb], 0, 0, 0);
     }
   }
-  // lane: output channels kt*64 + 16 w + 4 (lane / 16) + e, input channel ct*64 + 16 f + lane % 16
+  // lane: output channel kt*128 + 64 wk + 16 fa + 4 (lane / 16) + e, input channel ct*128 + 64 wc + 16 fb + lane % 16
   const long RSC = (long)taps * p.C;
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const int c = ct * TCH + 16 * f + (lane & 15);
+  for (int fa = 0; fa < 4; ++fa)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = kt * TK + 16 * wave + 4 * (lane >> 4) + e;
-      if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)tap * p.C + c] = acc[f][e];
+    for (int fb = 0; fb < 4; ++fb) {
+      const int c = ct * TCH + 64 * wc + 16 * fb + (lane & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kt * TK + 64 * wk + 16 * fa + 4 * (lane >> 4) + e;
+        if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)tap * p.C + c] = acc[fa][fb][e];
+      }
     }
-  }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, long n, int nsplit, int accumulate) {
@@ -102,10 +134,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 int pick_split(int K, int C, int taps, long P) {
+  // Slices are the only parallelism beyond the (few) output tiles, but every slice writes and re-reads a full fp32 copy of dW:
+  // aim at ~6 workgroups per CU while a slice keeps >= 24 steps; accept shorter slices (>= 8 steps) only to reach 2 per CU.
+  // (Measured on five of the network's shapes, tools/wgrad_probe.py; within ~15 % of the best split found for each.)
   const long tiles = (long)((K + TK - 1) / TK) * ((C + TCH - 1) / TCH) * taps;
-  long ns = (2048 + tiles - 1) / tiles;                        // ~8 workgroups per CU over the whole launch
-  const long maxs = (P + 8 * TPX - 1) / (8 * TPX);             // at least 8 steps per slice
-  if (ns > maxs) ns = maxs;
+  auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+  long ns = cdiv(1536, tiles);
+  ns = ns < cdiv(P, 24 * TPX) ? ns : cdiv(P, 24 * TPX);
+  long floor_ns = cdiv(512, tiles);
+  floor_ns = floor_ns < cdiv(P, 8 * TPX) ? floor_ns : cdiv(P, 8 * TPX);
+  if (ns < floor_ns) ns = floor_ns;
   return (int)(ns < 1 ? 1 : ns);
 }
 
