@@ -323,6 +323,11 @@ int64_t mtbt_channel_sum_workspace_bytes(int64_t pixels, int C);
 int mtbt_channel_sum(const void* x, const void* x2, int64_t pixels, int C, int32_t pixel_stride, int32_t pixel_stride2, int dtype,
                      float* out, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* out[p][c] = a[c] * x1[p][c] + b[c] * x2[p][c] + d[c] over dense [pixels][C] tensors (C % 8 == 0; f32 or bf16): the elementwise pass
+ * of a batch-statistic BatchNorm backward, dx = (gamma/sigma) (dy - mean(dy) - xhat mean(dy xhat)), written on (dy, pre-activation). */
+int mtbt_channel_affine2(const void* x1, const void* x2, const float* a, const float* b, const float* d, void* out, int64_t pixels, int C,
+                         int dtype, void* stream);
+
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
  * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */

@@ -102,3 +102,30 @@ def channel_sum(x: Act, out: torch.Tensor = None, accumulate: bool = False, time
                                  out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes,
                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_channel_sum")
     return out
+
+
+def batchnorm_train_backward(dz: Act, u: Act, gamma: torch.Tensor, beta: torch.Tensor, batch_var: torch.Tensor, eps: float):
+    """Backward of BatchNorm2d on BATCH statistics (the heads in `forward(x, "train")`, main_model.py:358-359) given dz = d loss /
+    d(BN output) and u = the BN output itself (the kept pre-activation): returns (dx as an Act, d gamma, d beta).
+        xhat = (u - beta) / gamma;  d beta = sum dz;  d gamma = sum dz * xhat;
+        dx = gamma / sigma * (dz - d beta / M - xhat * d gamma / M),  sigma = sqrt(batch_var + eps),  M = pixels per channel
+    Two deterministic channel reductions, a handful of [C]-sized tensor ops, one elementwise pass."""
+    import ctypes as C
+    lib = L.load()
+    dev = dz.buf.device
+    M = float(dz.N * dz.H * dz.W)
+    gamma, beta = gamma.float(), beta.float()
+    s1 = channel_sum(dz)                                # sum dz
+    s2 = channel_sum(dz, times=u)                       # sum dz * u
+    d_beta = s1
+    d_gamma = (s2 - beta * s1) / gamma
+    inv_sigma = torch.rsqrt(batch_var.float() + eps)
+    a = gamma * inv_sigma                               # coefficient of dz
+    b = -(d_gamma / M) * inv_sigma                      # coefficient of u:  -(gamma/sigma) * (d_gamma/M) / gamma
+    d = a * (-(s1 / M)) - b * beta                      # constant:          -(gamma/sigma) * d_beta/M + (d_gamma/M)/sigma * beta
+    out = Act.of(torch.empty_like(dz.buf))
+    a, b, d = a.contiguous(), b.contiguous(), d.contiguous()
+    L.check(lib.mtbt_channel_affine2(dz.ptr, u.ptr, a.data_ptr(), b.data_ptr(), d.data_ptr(), out.ptr, dz.N * dz.H * dz.W, dz.C, dz.code,
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_channel_affine2")
+    out._keep = (a, b, d)                               # the launch is asynchronous
+    return out, d_gamma, d_beta

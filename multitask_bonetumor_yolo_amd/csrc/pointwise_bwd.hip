@@ -31,6 +31,26 @@ __global__ __launch_bounds__(256) void act_backward_kernel(const T* __restrict__
   }
 }
 
+// out[p][c] = a[c] * x1[p][c] + b[c] * x2[p][c] + d[c]: the elementwise pass of a batch-statistic BatchNorm backward,
+//   dx = (gamma / sigma) * (dy - mean(dy) - xhat * mean(dy * xhat)),  xhat = (u - beta) / gamma
+// written on (dy, u) with per-channel coefficients the host forms from the two channel sums.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_affine2_kernel(const T* __restrict__ x1, const T* __restrict__ x2, const float* __restrict__ a,
+                                                              const float* __restrict__ b, const float* __restrict__ d, T* __restrict__ out,
+                                                              long P, int C) {
+  const int chunks = C >> 3;
+  const long n8 = P * chunks;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    float u[8], v[8];
+    ld8(x1 + i * 8, u);
+    ld8(x2 + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] = a[ch * 8 + k] * u[k] + b[ch * 8 + k] * v[k] + d[ch * 8 + k];
+    st8(out + i * 8, u);
+  }
+}
+
 constexpr int ROWS_PER_BLOCK = 256;   // pixels per workgroup in the first level
 
 // lane group = 8 channels (one 16-byte chunk); a workgroup sums ROWS_PER_BLOCK pixels of every chunk it is given
@@ -108,6 +128,26 @@ extern "C" int mtbt_channel_sum(const void* x, const void* x2, int64_t pixels, i
   else
     return MTBT_EINVAL;
   hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, (int)blocks, C, out, accumulate);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_channel_affine2(const void* x1, const void* x2, const float* a, const float* b, const float* d, void* out, int64_t pixels,
+                                    int C, int dtype, void* stream) {
+  if (!x1 || !x2 || !a || !b || !d || !out || pixels <= 0 || C <= 0 || C % 8) return MTBT_EINVAL;
+  if (!aligned16(x1) || !aligned16(x2) || !aligned16(out)) return MTBT_EALIGN;
+  const long n8 = pixels * (C / 8);
+  long blocks = (n8 + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MTBT_BF16)
+    hipLaunchKernelGGL(channel_affine2_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x1, (const bf16_t*)x2, a, b, d, (bf16_t*)out,
+                       (long)pixels, C);
+  else if (dtype == MTBT_F32)
+    hipLaunchKernelGGL(channel_affine2_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x1, (const float*)x2, a, b, d, (float*)out,
+                       (long)pixels, C);
+  else
+    return MTBT_EINVAL;
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

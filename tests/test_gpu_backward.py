@@ -181,3 +181,27 @@ def test_convblock_backward_composes(k):
     assert close(d_bias, blk.conv.bias.grad, 2e-2)
     assert close(d_beta, blk.bn.bias.grad, 2e-2)
     assert close(d_gamma, blk.bn.weight.grad, 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_train_backward(dtype):
+    """BatchNorm2d on batch statistics (ultralytics Conv inside the heads in train mode) followed by SiLU: dx, d gamma, d beta."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    torch.manual_seed(5)
+    N, C, H, W = 4, 64, 12, 10
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    x = (torch.randn(N, C, H, W) * 2 + 0.3).requires_grad_()
+    dy = torch.randn(N, C, H, W).to(dtype).float()
+    u_ref = bn(x)
+    F.silu(u_ref).backward(dy)
+    var = x.detach().var(dim=(0, 2, 3), unbiased=False)
+    u = Act.of(nhwc(u_ref.detach()).to(dtype))
+    dz = B.act_backward(Act.of(nhwc(dy).to(dtype)), u, L.ACT_SILU)
+    dx, dg, db = B.batchnorm_train_backward(dz, u, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), var.to(DEV), bn.eps)
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    rel = lambda got, want: (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
+    assert rel(dx.buf.permute(0, 3, 1, 2), x.grad) < tol
+    assert rel(dg, bn.weight.grad) < tol and rel(db, bn.bias.grad) < tol
