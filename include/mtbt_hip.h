@@ -328,6 +328,12 @@ int mtbt_channel_sum(const void* x, const void* x2, int64_t pixels, int C, int32
 int mtbt_channel_affine2(const void* x1, const void* x2, const float* a, const float* b, const float* d, void* out, int64_t pixels, int C,
                          int dtype, void* stream);
 
+/* LayerNorm backward over the channels of every pixel (timm ConvNeXt block `norm`, downsample LayerNorm2d): x, dy, dx (and the
+ * optional xhat output) dense [pixels][C], f32 or bf16; w = gamma [C] f32.  dx = rstd (g - mean_c g - xhat mean_c(g xhat)), g = dy gamma.
+ * d gamma = mtbt_channel_sum(dy, xhat), d beta = mtbt_channel_sum(dy). */
+int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, void* xhat, int64_t pixels, int C,
+                                 int dtype, void* stream);
+
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
  * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */

@@ -129,3 +129,18 @@ def batchnorm_train_backward(dz: Act, u: Act, gamma: torch.Tensor, beta: torch.T
                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_channel_affine2")
     out._keep = (a, b, d)                               # the launch is asynchronous
     return out, d_gamma, d_beta
+
+
+def layernorm_backward(x: Act, dy: Act, gamma: torch.Tensor, eps: float):
+    """Backward of a LayerNorm over the channels of each pixel (ConvNeXt `norm`, downsample LayerNorm2d): returns
+    (dx as an Act, d gamma, d beta) from the LN input x and dy."""
+    import ctypes as C
+    lib = L.load()
+    assert x.dense and dy.dense and x.code == dy.code and x.buf.shape == dy.buf.shape
+    dev = x.buf.device
+    dx, xhat = Act.of(torch.empty_like(x.buf)), Act.of(torch.empty_like(x.buf))
+    g = gamma.float().contiguous()
+    L.check(lib.mtbt_layernorm_backward_nhwc(x.ptr, dy.ptr, g.data_ptr(), eps, dx.ptr, xhat.ptr, x.N * x.H * x.W, x.C, x.code,
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_layernorm_backward_nhwc")
+    dx._keep = g
+    return dx, channel_sum(dy, times=xhat), channel_sum(dy)

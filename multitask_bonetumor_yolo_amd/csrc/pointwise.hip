@@ -201,6 +201,71 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const float* __restric
   }
 }
 
+// LayerNorm backward over the channels of a pixel (timm ConvNeXt `norm` / downsample LayerNorm2d), same lane-group layout as
+// the forward: recompute mean / rstd from x, g = dy * gamma,
+//     dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  xhat = (x - mean) * rstd
+// and optionally store xhat (for d gamma = sum_pixels dy * xhat through mtbt_channel_sum; d beta = sum_pixels dy).
+template <typename T, int MAXV, int LP>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w, float eps,
+                                     T* __restrict__ dx, T* __restrict__ xhat, long pixels, int C) {
+  constexpr int PPW = 64 / LP;
+  const int lane = threadIdx.x & 63, gl = lane % LP;
+  const long pix = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PPW + lane / LP;
+  const bool live = pix < pixels;
+  const int CH8 = C >> 3;
+  float v[MAXV][8], g[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
+      ld8<T>(x + pix * C + ch * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = group_sum<LP>(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(group_sum<LP>(q) / C + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
+      float gw[8];
+      ld8<float>(w + ch * 8, gw);
+      ld8<T>(dy + pix * C + ch * 8, g[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (v[i][e] - mean) * rstd;       // xhat
+        g[i][e] *= gw[e];
+        s1 += g[i][e];
+        s2 += g[i][e] * v[i][e];
+      }
+    }
+  }
+  const float m1 = group_sum<LP>(s1) / C, m2 = group_sum<LP>(s2) / C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = gl + i * LP;
+    if (live && ch < CH8) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - v[i][e] * m2);
+      st8<T>(dx + pix * C + ch * 8, o);
+      if (xhat) st8<T>(xhat + pix * C + ch * 8, v[i]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BiFPN fusion node: thread = (output pixel, 8-channel chunk).
 // Bilinear x2 (align_corners=False): src = (dst+.5)/2-.5 clamped at 0; i0=floor, i1=min(i0+1,last).
@@ -376,6 +441,30 @@ extern "C" int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b
   else return MTBT_EINVAL;
 #undef LN_BY_C
 #undef LN_LAUNCH
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, void* xhat, int64_t pixels, int C,
+                                            int dtype, void* stream) {
+  if (!x || !dy || !w || !dx || pixels <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (xhat && !aligned16(xhat))) return MTBT_EALIGN;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int CH8 = C / 8;
+  const int LP = CH8 <= 16 ? 16 : (CH8 <= 32 ? 32 : 64);
+  const long blocks = (pixels + 4 * (64 / LP) - 1) / (4 * (64 / LP));
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+#define LNB_LAUNCH(T, MAXV, LPV) \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, MAXV, LPV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, w, eps, (T*)dx, (T*)xhat, \
+                     (long)pixels, C)
+#define LNB_BY_C(T) \
+  do { if (LP == 16) LNB_LAUNCH(T, 1, 16); else if (LP == 32) LNB_LAUNCH(T, 1, 32); else if (CH8 <= 64) LNB_LAUNCH(T, 1, 64); \
+       else if (CH8 <= 128) LNB_LAUNCH(T, 2, 64); else LNB_LAUNCH(T, 4, 64); } while (0)
+  if (dtype == MTBT_F32) LNB_BY_C(float);
+  else if (dtype == MTBT_BF16) LNB_BY_C(bf16_t);
+  else return MTBT_EINVAL;
+#undef LNB_BY_C
+#undef LNB_LAUNCH
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

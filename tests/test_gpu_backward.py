@@ -205,3 +205,22 @@ def test_batchnorm_train_backward(dtype):
     rel = lambda got, want: (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
     assert rel(dx.buf.permute(0, 3, 1, 2), x.grad) < tol
     assert rel(dg, bn.weight.grad) < tol and rel(db, bn.bias.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [96, 384, 768])
+def test_layernorm_backward(dtype, C):
+    """timm ConvNeXt block norm: LayerNorm over channels (eps 1e-6) in NHWC."""
+    g = torch.Generator().manual_seed(C)
+    N, H, W = 2, 9, 7
+    x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.2).to(dtype).float().requires_grad_()
+    ln = torch.nn.LayerNorm(C, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.1)
+    dy = torch.randn(N, H, W, C, generator=g).to(dtype).float()
+    ln(x).backward(dy)
+    dx, dg, db = B.layernorm_backward(Act.of(x.detach().to(DEV, dtype)), Act.of(dy.to(DEV, dtype)), ln.weight.detach().to(DEV), 1e-6)
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    rel = lambda got, want: (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
+    assert rel(dx.buf, x.grad) < tol and rel(dg, ln.weight.grad) < tol and rel(db, ln.bias.grad) < tol
