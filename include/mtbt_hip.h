@@ -334,6 +334,13 @@ int mtbt_channel_affine2(const void* x1, const void* x2, const float* a, const f
 int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, void* xhat, int64_t pixels, int C,
                                  int dtype, void* stream);
 
+/* Weight gradient of a depthwise k x k convolution (stride 1, pad k/2; k = 3 or 7): dw[tap][c] (fp32, the forward tap layout [k*k][C])
+ * (+)= sum_p dy[p][c] * x[p shifted by the tap][c]; x, dy dense [N,H,W,C], f32 or bf16.  Deterministic.  (First version: one
+ * shifted channel-product reduction per tap.) */
+int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize);
+int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
  * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */

@@ -109,6 +109,8 @@ SYMBOLS = {
                                    C.c_int64, C.c_void_p]),
     "mtbt_channel_affine2": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_layernorm_backward_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_dwconv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 5),
+    "mtbt_dwconv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "mtbt_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -144,3 +144,18 @@ def layernorm_backward(x: Act, dy: Act, gamma: torch.Tensor, eps: float):
                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_layernorm_backward_nhwc")
     dx._keep = g
     return dx, channel_sum(dy, times=xhat), channel_sum(dy)
+
+
+def dwconv_wgrad(x: Act, dy: Act, ksize: int, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+    """Depthwise weight gradient as fp32 [k*k, C] (the forward tap layout) from x and dy [N,H,W,C]."""
+    import ctypes as C
+    lib = L.load()
+    assert x.dense and dy.dense and x.code == dy.code and x.buf.shape == dy.buf.shape
+    dev = x.buf.device
+    if out is None:
+        out = torch.empty(ksize * ksize, x.C, dtype=torch.float32, device=dev)
+    nbytes = lib.mtbt_dwconv_wgrad_workspace_bytes(x.N, x.H, x.W, x.C, ksize)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    L.check(lib.mtbt_dwconv_wgrad(x.ptr, dy.ptr, out.data_ptr(), x.N, x.H, x.W, x.C, ksize, x.code, int(accumulate), ws.data_ptr(), nbytes,
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_dwconv_wgrad")
+    return out

@@ -78,6 +78,33 @@ __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__
   }
 }
 
+// Depthwise weight gradient, first version: dW[tap][c] = sum_p dy[p][c] * x[p shifted by the tap][c] (zero outside the image) as one
+// shifted channel-product reduction per tap (grid.y = tap): 2 x k*k tensor reads instead of 2 -- a halo-tile version that forms all
+// taps from one staged tile is the follow-up.  partial: [workgroup][k*k*C].
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_partial(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C, int ks,
+                                                        float* __restrict__ partial) {
+  const int chunks = C >> 3, tap = blockIdx.y, r = tap / ks - ks / 2, sft = tap % ks - ks / 2;
+  const long P = (long)N * H * W;
+  const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK, p1 = min(P, p0 + ROWS_PER_BLOCK);
+  const long row = (long)ks * ks * C;
+  for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long p = p0; p < p1; ++p) {
+      const int n = (int)(p / ((long)H * W)), rem = (int)(p - (long)n * H * W);
+      const int y = rem / W + r, xx = rem % W + sft;
+      if ((unsigned)y >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+      float a[8], b[8];
+      ld8(dy + p * C + ch * 8, a);
+      ld8(x + (((long)n * H + y) * W + xx) * C + ch * 8, b);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += a[k] * b[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * row + (long)tap * C + ch * 8 + k] = s[k];
+  }
+}
+
 __global__ __launch_bounds__(256) void channel_sum_final(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
@@ -148,6 +175,33 @@ extern "C" int mtbt_channel_affine2(const void* x1, const void* x2, const float*
                        (long)pixels, C);
   else
     return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0) return 0;
+  return (((int64_t)N * H * W + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * (int64_t)ksize * ksize * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (ksize != 3 && ksize != 7)) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return MTBT_EALIGN;
+  if (workspace_bytes < mtbt_dwconv_wgrad_workspace_bytes(N, H, W, C, ksize)) return MTBT_EWORKSPACE;
+  const long blocks = ((long)N * H * W + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  const dim3 grid((unsigned)blocks, (unsigned)(ksize * ksize));
+  if (dtype == MTBT_BF16)
+    hipLaunchKernelGGL(dw_wgrad_partial<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, N, H, W, C, ksize, partial);
+  else if (dtype == MTBT_F32)
+    hipLaunchKernelGGL(dw_wgrad_partial<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, N, H, W, C, ksize, partial);
+  else
+    return MTBT_EINVAL;
+  const int n = ksize * ksize * C;
+  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, (int)blocks, n, dw, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

@@ -224,3 +224,94 @@ def test_layernorm_backward(dtype, C):
     tol = 2e-4 if dtype == torch.float32 else 3e-2
     rel = lambda got, want: (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
     assert rel(dx.buf, x.grad) < tol and rel(dg, ln.weight.grad) < tol and rel(db, ln.bias.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,k,H", [(96, 7, 18), (256, 3, 11)])
+def test_dwconv_wgrad(dtype, C, k, H):
+    g = torch.Generator().manual_seed(C * k)
+    N = 2
+    x = torch.randn(N, C, H, H, generator=g).to(dtype).float()
+    w = (torch.randn(C, 1, k, k, generator=g) / k).requires_grad_()
+    dy = torch.randn(N, C, H, H, generator=g).to(dtype).float()
+    (want,) = torch.autograd.grad(F.conv2d(x, w, None, 1, k // 2, groups=C), w, dy)
+    got = B.dwconv_wgrad(Act.of(nhwc(x).to(dtype)), Act.of(nhwc(dy).to(dtype)), k)
+    torch.cuda.synchronize()
+    want = want.view(C, k * k).t()
+    assert (got.cpu() - want).abs().max().item() <= 2e-4 * want.abs().max().item() + 1e-5
+
+
+def test_convnext_block_backward_composes():
+    """Backward of a whole ConvNeXt block (timm: dw 7x7 + bias -> LayerNorm -> Linear -> GELU -> Linear -> layer-scale -> + x) assembled
+    from the pieces, against torch autograd through the oracle block: dx and the gradient of every parameter.  bf16 activations."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    from oracle.convnext import ConvNeXtBlock
+    torch.manual_seed(21)
+    N, H, W, d = 2, 12, 12, 96
+    blk = ConvNeXtBlock(d)
+    with torch.no_grad():
+        blk.gamma.uniform_(0.2, 1.0)
+        blk.norm.weight.uniform_(0.5, 1.5); blk.norm.bias.normal_(0, 0.1)
+        for prm in (blk.conv_dw.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight):
+            prm.copy_(prm.bfloat16().float())
+    x = torch.randn(N, d, H, W).bfloat16().float().requires_grad_()
+    dy = torch.randn(N, d, H, W).bfloat16().float()
+    blk(x).backward(dy)
+
+    bf = torch.bfloat16
+    dev = torch.device(DEV)
+    ones = lambda c: torch.ones(c, device=DEV)
+    zeros = lambda c: torch.zeros(c, device=DEV)
+    new = lambda c: Act.of(torch.empty(N, H, W, c, dtype=bf, device=DEV))
+    taps = blk.conv_dw.weight.detach().view(d, 49).t().contiguous().to(DEV, bf)
+    W1 = blk.mlp.fc1.weight.detach().to(DEV, bf).contiguous()            # [4d, d] = packed [K, C]
+    W2 = blk.mlp.fc2.weight.detach().to(DEV, bf).contiguous()            # [d, 4d]
+    gam = blk.gamma.detach().to(DEV)
+    # ---- a training forward that keeps what the backward needs ----
+    xa = Act.of(nhwc(x.detach()).to(bf))
+    a, t, h, hg, o = new(d), new(d), new(4 * d), new(4 * d), new(d)
+    p = Plan(dev)
+    p.dwconv(xa, taps, a, 7, scale=ones(d), shift=blk.conv_dw.bias.detach().to(DEV))
+    p.layernorm(a, blk.norm.weight.detach().to(DEV), blk.norm.bias.detach().to(DEV), 1e-6, t)
+    p.conv(t, W1, h, shift=blk.mlp.fc1.bias.detach().to(DEV))
+    p.conv(t, W1, hg, shift=blk.mlp.fc1.bias.detach().to(DEV), act=L.ACT_GELU)
+    p.conv(hg, W2, o, shift=blk.mlp.fc2.bias.detach().to(DEV))
+    run(p)
+    # ---- backward ----
+    dya = Act.of(nhwc(dy).to(bf))
+    d_gamma = B.channel_sum(dya, times=o)
+
+    def affine2(x1, x2, c1, c2):
+        import ctypes as C
+        out = Act.of(torch.empty_like(x1.buf))
+        z = zeros(x1.C)
+        L.check(L.load().mtbt_channel_affine2(x1.ptr, x2.ptr, c1.data_ptr(), c2.data_ptr(), z.data_ptr(), out.ptr, N * H * W, x1.C, x1.code,
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "affine2")
+        torch.cuda.synchronize()
+        return out
+    do = affine2(dya, dya, gam, zeros(d))                                 # d o = dy * gamma
+    dW2, db2 = B.conv_wgrad(hg, do, R=1, S=1, pad=0), B.channel_sum(do)
+    dhg, dt, dxdw = new(4 * d), new(d), new(d)
+    p2 = Plan(dev)
+    B.conv_dgrad(p2, do, B.dgrad_weight(W2, 1, 1), dhg, R=1, S=1, pad=0)
+    run(p2)
+    dh = B.act_backward(dhg, h, L.ACT_GELU)
+    dW1, db1 = B.conv_wgrad(t, dh, R=1, S=1, pad=0), B.channel_sum(dh)
+    p3 = Plan(dev)
+    B.conv_dgrad(p3, dh, B.dgrad_weight(W1, 1, 1), dt, R=1, S=1, pad=0)
+    run(p3)
+    da, d_lnw, d_lnb = B.layernorm_backward(a, dt, blk.norm.weight.detach().to(DEV), 1e-6)
+    d_taps, d_dwb = B.dwconv_wgrad(xa, da, 7), B.channel_sum(da)
+    p4 = Plan(dev)
+    B.dwconv_dgrad(p4, da, B.dwconv_dgrad_weight(taps, 7), dxdw, 7, ones(d), zeros(d))
+    run(p4)
+    dx = affine2(dxdw, dya, ones(d), ones(d))                             # + the residual path
+
+    def close(got, want, tol=4e-2):
+        return (got.float().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
+    assert close(dx.buf.permute(0, 3, 1, 2), x.grad)
+    assert close(d_gamma, blk.gamma.grad)
+    assert close(dW2, blk.mlp.fc2.weight.grad) and close(db2, blk.mlp.fc2.bias.grad)
+    assert close(dW1, blk.mlp.fc1.weight.grad) and close(db1, blk.mlp.fc1.bias.grad)
+    assert close(d_lnw, blk.norm.weight.grad) and close(d_lnb, blk.norm.bias.grad)
+    assert close(d_taps, blk.conv_dw.weight.grad.view(d, 49).t()) and close(d_dwb, blk.conv_dw.bias.grad)
