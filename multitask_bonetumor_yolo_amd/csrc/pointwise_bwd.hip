@@ -53,29 +53,66 @@ __global__ __launch_bounds__(256) void channel_affine2_kernel(const T* __restric
 
 constexpr int ROWS_PER_BLOCK = 256;   // pixels per workgroup in the first level
 
-// lane group = 8 channels (one 16-byte chunk); a workgroup sums ROWS_PER_BLOCK pixels of every chunk it is given
+// A thread owns one 16-byte chunk (8 channels) of a pixel; with fewer than 256 chunks per pixel the workgroup's threads split into
+// row groups that walk the workgroup's ROWS_PER_BLOCK pixels in parallel and are then added in row-group order through LDS
+// (deterministic).  `fetch(p, ch, v)` returns false when pixel p contributes nothing.
+template <typename F>
+__device__ __forceinline__ void rows_reduce(long p0, long p1, int chunks, float* __restrict__ dst /* [chunks*8] of this workgroup */, F fetch) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  if (chunks >= 256) {
+    for (int ch = tid; ch < chunks; ch += 256) {
+      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (long p = p0; p < p1; ++p) {
+        float v[8];
+        if (fetch(p, ch, v)) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s[k] += v[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dst[ch * 8 + k] = s[k];
+    }
+    return;
+  }
+  const int rpp = 256 / chunks, rg = tid / chunks, ch = tid - rg * chunks;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rg < rpp) {
+    for (long p = p0 + rg; p < p1; p += rpp) {
+      float v[8];
+      if (fetch(p, ch, v)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(rg * chunks + ch) * 8 + k] = s[k];
+  }
+  __syncthreads();
+  if (rg == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t = 0.f;
+      for (int g = 0; g < rpp; ++g) t += red[(g * chunks + ch) * 8 + k];
+      dst[ch * 8 + k] = t;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__ x, const T* __restrict__ x2, long P, int C, int ld, int ld2,
                                                            float* __restrict__ partial) {
-  const int chunks = C >> 3;
   const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK, p1 = min(P, p0 + ROWS_PER_BLOCK);
-  for (int ch = threadIdx.x; ch < chunks; ch += 256) {
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long p = p0; p < p1; ++p) {
-      float v[8];
-      ld8(x + p * ld + ch * 8, v);
-      if (x2) {
-        float u[8];
-        ld8(x2 + p * ld2 + ch * 8, u);
+  rows_reduce(p0, p1, C >> 3, partial + (long)blockIdx.x * C, [&](long p, int ch, float (&v)[8]) {
+    ld8(x + p * ld + ch * 8, v);
+    if (x2) {
+      float u[8];
+      ld8(x2 + p * ld2 + ch * 8, u);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] *= u[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s[k] += v[k];
+      for (int k = 0; k < 8; ++k) v[k] *= u[k];
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * C + ch * 8 + k] = s[k];
-  }
+    return true;
+  });
 }
 
 // Depthwise weight gradient, first version: dW[tap][c] = sum_p dy[p][c] * x[p shifted by the tap][c] (zero outside the image) as one
@@ -84,33 +121,31 @@ __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void dw_wgrad_partial(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C, int ks,
                                                         float* __restrict__ partial) {
-  const int chunks = C >> 3, tap = blockIdx.y, r = tap / ks - ks / 2, sft = tap % ks - ks / 2;
+  const int tap = blockIdx.y, r = tap / ks - ks / 2, sft = tap % ks - ks / 2;
   const long P = (long)N * H * W;
   const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK, p1 = min(P, p0 + ROWS_PER_BLOCK);
-  const long row = (long)ks * ks * C;
-  for (int ch = threadIdx.x; ch < chunks; ch += 256) {
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long p = p0; p < p1; ++p) {
-      const int n = (int)(p / ((long)H * W)), rem = (int)(p - (long)n * H * W);
-      const int y = rem / W + r, xx = rem % W + sft;
-      if ((unsigned)y >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-      float a[8], b[8];
-      ld8(dy + p * C + ch * 8, a);
-      ld8(x + (((long)n * H + y) * W + xx) * C + ch * 8, b);
+  rows_reduce(p0, p1, C >> 3, partial + (long)blockIdx.x * ks * ks * C + (long)tap * C, [&](long p, int ch, float (&v)[8]) {
+    const int n = (int)(p / ((long)H * W)), rem = (int)(p - (long)n * H * W);
+    const int y = rem / W + r, xx = rem % W + sft;
+    if ((unsigned)y >= (unsigned)H || (unsigned)xx >= (unsigned)W) return false;
+    float b[8];
+    ld8(dy + p * C + ch * 8, v);
+    ld8(x + (((long)n * H + y) * W + xx) * C + ch * 8, b);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s[k] += a[k] * b[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * row + (long)tap * C + ch * 8 + k] = s[k];
-  }
+    for (int k = 0; k < 8; ++k) v[k] *= b[k];
+    return true;
+  });
 }
 
+// second level: one wave per output element; its lanes stride over the workgroup partials and are combined by a butterfly (fixed
+// order: deterministic).  A serial loop per element took longer than the first level once there were ~1000 partial rows.
 __global__ __launch_bounds__(256) void channel_sum_final(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = accumulate ? out[c] : 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(long)b * C + c];
-  out[c] = s;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;                     // whole waves leave together
+  float s = 0.f;
+  for (int b = lane; b < blocks; b += 64) s += partial[(long)b * C + c];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace
@@ -154,7 +189,7 @@ extern "C" int mtbt_channel_sum(const void* x, const void* x2, int64_t pixels, i
     hipLaunchKernelGGL(channel_sum_partial<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, (const float*)x2, (long)pixels, C, pixel_stride, pixel_stride2, partial);
   else
     return MTBT_EINVAL;
-  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, (int)blocks, C, out, accumulate);
+  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, (int)blocks, C, out, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -201,7 +236,7 @@ extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N
   else
     return MTBT_EINVAL;
   const int n = ksize * ksize * C;
-  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, (int)blocks, n, dw, accumulate);
+  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, (int)blocks, n, dw, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
