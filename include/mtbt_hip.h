@@ -335,8 +335,8 @@ int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, 
                                  int dtype, void* stream);
 
 /* Weight gradient of a depthwise k x k convolution (stride 1, pad k/2; k = 3 or 7): dw[tap][c] (fp32, the forward tap layout [k*k][C])
- * (+)= sum_p dy[p][c] * x[p shifted by the tap][c]; x, dy dense [N,H,W,C], f32 or bf16.  Deterministic.  (First version: one
- * shifted channel-product reduction per tap.) */
+ * (+)= sum_p dy[p][c] * x[p shifted by the tap][c]; x, dy dense [N,H,W,C], f32 or bf16.  Deterministic.  (One pass per filter
+ * row: dy is read once and x k times per row.) */
 int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize);
 int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate, void* workspace,
                       int64_t workspace_bytes, void* stream);

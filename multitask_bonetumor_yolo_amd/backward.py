@@ -10,6 +10,8 @@ backward pass.  No new GEMM kernel is needed for any of 
 fp32 out, deterministic split reduction).  These are the linear parts only: the activation derivative on the way in and the
 normalisation backward are not built yet.  Everything here appends launches to an `engine.Plan`; weights are re-laid out once by the
 `*_weight` helpers (device tensors, any dtype the kernels take)."""
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -55,7 +57,6 @@ def dwconv_dgrad(plan: Plan, dy: Act, w_flipped: torch.Tensor, dx: Act, ksize: i
 def conv_wgrad(x: Act, dy: Act, *, R: int, S: int, pad: int, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
     """dW of a stride-1 'same' convolution as fp32 [K, R*S*C] (the packed forward layout) from x [N,H,W,C] and dy [N,H,W,K], both
     bf16.  `out` may be a view into a flat gradient bucket; `accumulate=True` adds to it.  Runs on the current stream."""
-    import ctypes as C
     lib = L.load()
     if x.code != L.BF16 or dy.code != L.BF16:
         raise NotImplementedError("conv_wgrad: bf16 operands only")
@@ -75,7 +76,6 @@ def conv_wgrad(x: Act, dy: Act, *, R: int, S: int, pad: int, out: torch.Tensor =
 
 def act_backward(dy: Act, z: Act, act: int, out: Act = None) -> Act:
     """dz = dy * act'(z) (z = pre-activation), dense NHWC tensors of one dtype.  Runs on the current stream."""
-    import ctypes as C
     lib = L.load()
     assert dy.dense and z.dense and dy.code == z.code and dy.buf.shape == z.buf.shape
     if out is None:
@@ -89,7 +89,6 @@ def act_backward(dy: Act, z: Act, act: int, out: Act = None) -> Act:
 def channel_sum(x: Act, out: torch.Tensor = None, accumulate: bool = False, times: Act = None) -> torch.Tensor:
     """fp32 [C] = sum over all pixels of x [N,H,W,C] (bias / shift gradient), or of x * times (scale gradient).  `out` may be a view
     into a gradient bucket."""
-    import ctypes as C
     lib = L.load()
     assert x.dense and (times is None or (times.dense and times.code == x.code and times.C == x.C))
     dev = x.buf.device
@@ -110,7 +109,6 @@ def batchnorm_train_backward(dz: Act, u: Act, gamma: torch.Tensor, beta: torch.T
         xhat = (u - beta) / gamma;  d beta = sum dz;  d gamma = sum dz * xhat;
         dx = gamma / sigma * (dz - d beta / M - xhat * d gamma / M),  sigma = sqrt(batch_var + eps),  M = pixels per channel
     Two deterministic channel reductions, a handful of [C]-sized tensor ops, one elementwise pass."""
-    import ctypes as C
     lib = L.load()
     dev = dz.buf.device
     M = float(dz.N * dz.H * dz.W)
@@ -134,7 +132,6 @@ def batchnorm_train_backward(dz: Act, u: Act, gamma: torch.Tensor, beta: torch.T
 def layernorm_backward(x: Act, dy: Act, gamma: torch.Tensor, eps: float):
     """Backward of a LayerNorm over the channels of each pixel (ConvNeXt `norm`, downsample LayerNorm2d): returns
     (dx as an Act, d gamma, d beta) from the LN input x and dy."""
-    import ctypes as C
     lib = L.load()
     assert x.dense and dy.dense and x.code == dy.code and x.buf.shape == dy.buf.shape
     dev = x.buf.device
@@ -148,7 +145,6 @@ def layernorm_backward(x: Act, dy: Act, gamma: torch.Tensor, eps: float):
 
 def dwconv_wgrad(x: Act, dy: Act, ksize: int, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
     """Depthwise weight gradient as fp32 [k*k, C] (the forward tap layout) from x and dy [N,H,W,C]."""
-    import ctypes as C
     lib = L.load()
     assert x.dense and dy.dense and x.code == dy.code and x.buf.shape == dy.buf.shape
     dev = x.buf.device

@@ -115,26 +115,71 @@ __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__
   });
 }
 
-// Depthwise weight gradient, first version: dW[tap][c] = sum_p dy[p][c] * x[p shifted by the tap][c] (zero outside the image) as one
-// shifted channel-product reduction per tap (grid.y = tap): 2 x k*k tensor reads instead of 2 -- a halo-tile version that forms all
-// taps from one staged tile is the follow-up.  partial: [workgroup][k*k*C].
-template <typename T>
-__global__ __launch_bounds__(256) void dw_wgrad_partial(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C, int ks,
+// Depthwise weight gradient: dW[tap][c] = sum_p dy[p][c] * x[p shifted by the tap][c] (zero outside the image).  grid.y = filter ROW:
+// a thread keeps the KS taps of that row for its 8 channels, so dy is read once and x KS times per row (8 instead of 14 tensor reads
+// per row of a 7x7 filter).  Row groups as in rows_reduce; partial: [workgroup][k*k*C].  A halo-tile version that forms all taps from
+// one staged tile is the follow-up.
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dw_wgrad_partial(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
                                                         float* __restrict__ partial) {
-  const int tap = blockIdx.y, r = tap / ks - ks / 2, sft = tap % ks - ks / 2;
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x, chunks = C >> 3, fr = blockIdx.y, r = fr - KS / 2;
+  const bool par = chunks < 256;
+  const int rpp = par ? 256 / chunks : 1, rg = par ? tid / chunks : 0, ch0 = par ? tid - rg * chunks : tid;
   const long P = (long)N * H * W;
   const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK, p1 = min(P, p0 + ROWS_PER_BLOCK);
-  rows_reduce(p0, p1, C >> 3, partial + (long)blockIdx.x * ks * ks * C + (long)tap * C, [&](long p, int ch, float (&v)[8]) {
-    const int n = (int)(p / ((long)H * W)), rem = (int)(p - (long)n * H * W);
-    const int y = rem / W + r, xx = rem % W + sft;
-    if ((unsigned)y >= (unsigned)H || (unsigned)xx >= (unsigned)W) return false;
-    float b[8];
-    ld8(dy + p * C + ch * 8, v);
-    ld8(x + (((long)n * H + y) * W + xx) * C + ch * 8, b);
+  float* dst = partial + (long)blockIdx.x * KS * KS * C + (long)fr * KS * C;
+  for (int ch = ch0; ch < chunks; ch += (par ? chunks : 256)) {     // row-group mode: exactly one trip for every thread
+    float s[KS][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] *= b[k];
-    return true;
-  });
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[t][k] = 0.f;
+    if (rg < rpp) {
+      for (long p = p0 + rg; p < p1; p += rpp) {
+        const int n = (int)(p / ((long)H * W)), rem = (int)(p - (long)n * H * W);
+        const int y = rem / W + r, xx = rem % W;
+        if ((unsigned)y >= (unsigned)H) continue;
+        float a[8];
+        ld8(dy + p * C + ch * 8, a);
+        const T* xr = x + (((long)n * H + y) * W) * C + ch * 8;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+          const int ix = xx + t - KS / 2;
+          if ((unsigned)ix < (unsigned)W) {
+            float b[8];
+            ld8(xr + (long)ix * C, b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[t][k] += a[k] * b[k];
+          }
+        }
+      }
+    }
+    if (!par) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[(long)t * C + ch * 8 + k] = s[t][k];
+    } else {
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        if (rg < rpp) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) red[(rg * chunks + ch) * 8 + k] = s[t][k];
+        }
+        __syncthreads();
+        if (rg == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float v = 0.f;
+            for (int g = 0; g < rpp; ++g) v += red[(g * chunks + ch) * 8 + k];
+            dst[(long)t * C + ch * 8 + k] = v;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
 }
 
 // second level: one wave per output element; its lanes stride over the workgroup partials and are combined by a butterfly (fixed
@@ -228,13 +273,12 @@ extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
-  const dim3 grid((unsigned)blocks, (unsigned)(ksize * ksize));
-  if (dtype == MTBT_BF16)
-    hipLaunchKernelGGL(dw_wgrad_partial<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, N, H, W, C, ksize, partial);
-  else if (dtype == MTBT_F32)
-    hipLaunchKernelGGL(dw_wgrad_partial<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, N, H, W, C, ksize, partial);
-  else
-    return MTBT_EINVAL;
+  const dim3 grid((unsigned)blocks, (unsigned)ksize);
+#define DWW(T, KSV) hipLaunchKernelGGL((dw_wgrad_partial<T, KSV>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, N, H, W, C, partial)
+  if (dtype == MTBT_BF16) { if (ksize == 7) DWW(bf16_t, 7); else DWW(bf16_t, 3); }
+  else if (dtype == MTBT_F32) { if (ksize == 7) DWW(float, 7); else DWW(float, 3); }
+  else return MTBT_EINVAL;
+#undef DWW
   const int n = ksize * ksize * C;
   hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, (int)blocks, n, dw, accumulate);
   MTBT_LAUNCH_CHECK();

@@ -48,7 +48,7 @@ for H, d in [(160, 96), (80, 192), (40, 384), (20, 768)]:
     rows.append(("bwd fc1 wgrad", timed(lambda: B.conv_wgrad(tt, h, R=1, S=1, pad=0))))
     rows.append(("bwd fc1 dgrad", timed(plan_of(lambda p: B.conv_dgrad(p, h, w1d, tt, R=1, S=1, pad=0)))))
     rows.append(("bwd LayerNorm (+ d gamma, d beta)", timed(lambda: B.layernorm_backward(a, tt, one, 1e-6))))
-    rows.append(("bwd dw7x7 wgrad (first version)", timed(lambda: B.dwconv_wgrad(x, a, 7))))
+    rows.append(("bwd dw7x7 wgrad (one pass per filter row)", timed(lambda: B.dwconv_wgrad(x, a, 7))))
     tf = B.dwconv_dgrad_weight(taps, 7)
     rows.append(("bwd dw7x7 dgrad", timed(plan_of(lambda p: B.dwconv_dgrad(p, a, tf, o, 7, one, zero)))))
     fwd, bwd = sum(v for _, v in rows[:nf]), sum(v for _, v in rows[nf:])
