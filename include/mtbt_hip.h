@@ -304,13 +304,13 @@ int64_t mtbt_seg_confusion_workspace_bytes(int B);
 int mtbt_seg_confusion(const float* logits, const float* gt, int B, int64_t n_per_image, int64_t* counts, float* prob_sum,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Weight gradient of a stride-1 "same" k x k convolution (2 * pad == R - 1 == S - 1; R = S = 1 included), bf16 operands:
- *   dw[k][r][s][c] (fp32, packed [K][R*S*C] like the forward weight) (+)= sum_p dy[p][k] * x[p shifted by (r - pad, s - pad)][c]
- * x [N,H,W,C], dy [N,H,W,K] NHWC with pixel / batch strides in elements (multiples of 8; C % 8 == K % 8 == 0).  accumulate != 0
+/* Weight gradient of a k x k convolution (any stride / padding; 1x1 and the 2x2 stride-2 downsample included), bf16 operands:
+ *   dw[k][r][s][c] (fp32, packed [K][R*S*C] like the forward weight) (+)= sum_p dy[p][k] * x[n][y*stride + r - pad][x*stride + s - pad][c]
+ * x [N,H,W,C], dy [N,Ho,Wo,K] (Ho = (H + 2 pad - R) / stride + 1) NHWC with pixel / batch strides in elements (multiples of 8; C % 8 == K % 8 == 0).  accumulate != 0
  * adds to dw (gradient accumulation into a flat bucket).  Deterministic: per-slice fp32 partials in `workspace`
  * (>= mtbt_conv_wgrad_workspace_bytes) summed in a fixed order.  This is what autograd computes for `Conv2d.weight.grad`. */
 int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S);
-int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad,
+int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
                     int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 

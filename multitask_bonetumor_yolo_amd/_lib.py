@@ -101,7 +101,7 @@ SYMBOLS = {
     "mtbt_seg_confusion_workspace_bytes": (C.c_int64, [C.c_int]),
     "mtbt_seg_confusion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mtbt_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 7),
-    "mtbt_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 8 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
+    "mtbt_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
     "mtbt_act_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_channel_sum_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),

@@ -6,7 +6,7 @@ backward pass.  No new GEMM kernel is needed for any of 
   2 x 2, stride 2    dX = conv_transpose(dY, W): the OUT_CONVT2X2 scatter mode of the same kernel   (ConvNeXt downsample)
   depthwise k x k    the depthwise kernel on dY with the taps flipped                                (mtbt_dwconv_nhwc)
 
-`conv_wgrad` is the weight gradient of the stride-1 convolutions (csrc/wgrad.hip: transposed LDS reads feed the MFMA, bf16 in,
+`conv_wgrad` is the weight gradient of the dense convolutions (any stride) (csrc/wgrad.hip: transposed LDS reads feed the MFMA, bf16 in,
 fp32 out, deterministic split reduction).  These are the linear parts only: the activation derivative on the way in and the
 normalisation backward are not built yet.  Everything here appends launches to an `engine.Plan`; weights are re-laid out once by the
 `*_weight` helpers (device tensors, any dtype the kernels take)."""
@@ -54,13 +54,13 @@ def dwconv_dgrad(plan: Plan, dy: Act, w_flipped: torch.Tensor, dx: Act, ksize: i
     return plan.dwconv(dy, w_flipped, dx, ksize, scale=ones, shift=zeros, name=name)
 
 
-def conv_wgrad(x: Act, dy: Act, *, R: int, S: int, pad: int, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
-    """dW of a stride-1 'same' convolution as fp32 [K, R*S*C] (the packed forward layout) from x [N,H,W,C] and dy [N,H,W,K], both
+def conv_wgrad(x: Act, dy: Act, *, R: int, S: int, pad: int, stride: int = 1, out: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
+    """dW of a convolution (any stride; the ConvNeXt 2x2 / stride-2 downsample included) as fp32 [K, R*S*C] (the packed forward layout) from x [N,H,W,C] and dy [N,H,W,K], both
     bf16.  `out` may be a view into a flat gradient bucket; `accumulate=True` adds to it.  Runs on the current stream."""
     lib = L.load()
     if x.code != L.BF16 or dy.code != L.BF16:
         raise NotImplementedError("conv_wgrad: bf16 operands only")
-    assert (x.N, x.H, x.W) == (dy.N, dy.H, dy.W)
+    assert x.N == dy.N and (dy.H, dy.W) == ((x.H + 2 * pad - R) // stride + 1, (x.W + 2 * pad - S) // stride + 1)
     K, Cc = dy.C, x.C
     dev = x.buf.device
     if out is None:
@@ -68,7 +68,7 @@ def conv_wgrad(x: Act, dy: Act, *, R: int, S: int, pad: int, out: torch.Tensor =
     assert out.dtype == torch.float32 and out.numel() == K * R * S * Cc and out.is_contiguous()
     nbytes = lib.mtbt_conv_wgrad_workspace_bytes(x.N, x.H, x.W, Cc, K, R, S)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-    L.check(lib.mtbt_conv_wgrad(x.ptr, dy.ptr, out.data_ptr(), x.N, x.H, x.W, Cc, K, R, S, pad, x.batch_stride, x.ld, dy.batch_stride, dy.ld,
+    L.check(lib.mtbt_conv_wgrad(x.ptr, dy.ptr, out.data_ptr(), x.N, x.H, x.W, Cc, K, R, S, pad, stride, x.batch_stride, x.ld, dy.batch_stride, dy.ld,
                                 x.code, int(accumulate), ws.data_ptr(), nbytes, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
             "mtbt_conv_wgrad")
     return out

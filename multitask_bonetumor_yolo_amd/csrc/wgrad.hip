@@ -1,5 +1,5 @@
-// Weight gradient of a stride-1 k x k convolution, bf16 operands, fp32 result:
-//     dW[k][r][s][c] = sum over pixels p = (n, y, x) of  dY[p][k] * X[n][y + r - pad][x + s - pad][c]
+// Weight gradient of a k x k convolution of any stride, bf16 operands, fp32 result:
+//     dW[k][r][s][c] = sum over output pixels p = (n, y, x) of  dY[p][k] * X[n][y * stride + r - pad][x * stride + s - pad][c]
 // The reduction runs over the NHWC-SLOW index, so both MFMA operands arrive transposed with respect to how the forward
 // kernels read them.  gfx950's ds_read_b64_tr_b16 delivers a 4-row x 16-column block of 16-bit elements column-major to a
 // 16-lane group, which is exactly one half of a 16x16x32 operand fragment, so the tiles are staged in their natural layout
@@ -23,7 +23,7 @@ constexpr int TK = 128, TCH = 128, TPX = 64, LPT = TPX / 16;   // LPT: 16-byte l
 
 struct WgP {
   const bf16_t* x; const bf16_t* dy; float* partial;
-  int N, H, W, C, K, R, S, pad;
+  int N, H, W, C, K, R, S, pad, stride, Ho, Wo;
   long x_bs, dy_bs; int ldx, ldy;
   long P, per;        // pixels, pixels per slice (multiple of TPX)
   int nsplit, ktiles, ctiles;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wc = wave >> 1;            // wave tile: 64 output channels x 64 input channels
   const int row = tid >> 4, chunk = tid & 15;         // staging: tile row (pixel of the pass), 16-byte chunk (8 channels)
-  const int HW = p.H * p.W;
+  const int HW = p.Ho * p.Wo;                       // pixels are those of dY
   const long p0 = (long)split * p.per, p1 = min(p.P, p0 + p.per);
   const int kch = kt * TK + chunk * 8, cch = ct * TCH + chunk * 8;
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
       vdy[i] = vx[i] = uint4{0u, 0u, 0u, 0u};
       if (pix < p1) {
         const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
-        const int y = rem / p.W, xx = rem - y * p.W;
+        const int y = rem / p.Wo, xx = rem - y * p.Wo;
         if (kch < p.K) vdy[i] = *reinterpret_cast<const uint4*>(p.dy + (long)n * p.dy_bs + (long)rem * p.ldy + kch);
-        const int iy = y + r - p.pad, ix = xx + s - p.pad;
+        const int iy = y * p.stride + r - p.pad, ix = xx * p.stride + s - p.pad;
         if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cch < p.C)
           vx[i] = *reinterpret_cast<const uint4*>(p.x + (long)n * p.x_bs + ((long)iy * p.W + ix) * p.ldx + cch);
       }
@@ -151,22 +151,24 @@ int pick_split(int K, int C, int taps, long P) {
 
 extern "C" int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return 0;
+  // an upper bound for every stride: slices never outnumber those of the stride-1 case (fewer dY pixels)
   return (int64_t)pick_split(K, C, R * S, (long)N * H * W) * K * R * S * C * (int64_t)sizeof(float);
 }
 
-extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad,
+extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
                                int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
                                int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return MTBT_EINVAL;
   if (dtype != MTBT_BF16 || C % 8 || K % 8 || x_pixel_stride % 8 || dy_pixel_stride % 8 || x_batch_stride % 8 || dy_batch_stride % 8) return MTBT_EINVAL;
-  if (2 * pad != R - 1 || 2 * pad != S - 1) return MTBT_EINVAL;          // stride-1 "same" convolutions
+  if (stride < 1 || pad < 0 || H + 2 * pad < R || W + 2 * pad < S) return MTBT_EINVAL;
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return MTBT_EALIGN;
   if (workspace_bytes < mtbt_conv_wgrad_workspace_bytes(N, H, W, C, K, R, S)) return MTBT_EWORKSPACE;
   WgP p;
   p.x = reinterpret_cast<const bf16_t*>(x); p.dy = reinterpret_cast<const bf16_t*>(dy); p.partial = reinterpret_cast<float*>(workspace);
-  p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.pad = pad;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.pad = pad; p.stride = stride; p.Ho = Ho; p.Wo = Wo;
   p.x_bs = x_batch_stride; p.dy_bs = dy_batch_stride; p.ldx = x_pixel_stride; p.ldy = dy_pixel_stride;
-  p.P = (long)N * H * W;
+  p.P = (long)N * Ho * Wo;
   p.nsplit = pick_split(K, C, R * S, p.P);
   p.per = ((p.P + p.nsplit - 1) / p.nsplit + TPX - 1) / TPX * TPX;
   p.ktiles = (K + TK - 1) / TK; p.ctiles = (C + TCH - 1) / TCH;

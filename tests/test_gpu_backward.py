@@ -315,3 +315,17 @@ def test_convnext_block_backward_composes():
     assert close(dW1, blk.mlp.fc1.weight.grad) and close(db1, blk.mlp.fc1.bias.grad)
     assert close(d_lnw, blk.norm.weight.grad) and close(d_lnb, blk.norm.bias.grad)
     assert close(d_taps, blk.conv_dw.weight.grad.view(d, 49).t()) and close(d_dwb, blk.conv_dw.bias.grad)
+
+
+def test_conv_wgrad_strided_downsample():
+    """ConvNeXt downsample conv: 2x2, stride 2, no padding."""
+    g = torch.Generator().manual_seed(8)
+    N, H, W, C, K = 2, 12, 20, 96, 192
+    x = torch.randn(N, C, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(K, C, 2, 2, generator=g) / (4 * C) ** 0.5).requires_grad_()
+    dy = torch.randn(N, K, H // 2, W // 2, generator=g).bfloat16().float()
+    (want,) = torch.autograd.grad(F.conv2d(x, w, None, 2, 0), w, dy)
+    want = want.permute(0, 2, 3, 1).reshape(K, -1)
+    got = B.conv_wgrad(Act.of(nhwc(x).bfloat16()), Act.of(nhwc(dy).bfloat16()), R=2, S=2, pad=0, stride=2)
+    torch.cuda.synchronize()
+    assert (got.cpu() - want).abs().max().item() <= 2e-4 * want.abs().max().item() + 1e-5
