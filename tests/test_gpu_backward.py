@@ -329,3 +329,43 @@ def test_conv_wgrad_strided_downsample():
     got = B.conv_wgrad(Act.of(nhwc(x).bfloat16()), Act.of(nhwc(dy).bfloat16()), R=2, S=2, pad=0, stride=2)
     torch.cuda.synchronize()
     assert (got.cpu() - want).abs().max().item() <= 2e-4 * want.abs().max().item() + 1e-5
+
+
+def test_head_conv_train_mode_backward_composes():
+    """ultralytics Conv as the heads run it in `forward(x, "train")`: Conv2d(3x3, no bias) -> BatchNorm2d on BATCH statistics
+    (mtbt_bn_train_nhwc) -> SiLU.  Backward from the pieces vs autograd: dx, dW, d gamma, d beta."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    torch.manual_seed(31)
+    N, H, W, C, K = 4, 20, 20, 64, 64
+    conv = torch.nn.Conv2d(C, K, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(K, eps=1e-3, momentum=0.03).train()
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.bfloat16().float())
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    x = torch.randn(N, C, H, W).bfloat16().float().requires_grad_()
+    dy = torch.randn(N, K, H, W).bfloat16().float()
+    F.silu(bn(conv(x))).backward(dy)
+
+    import copy
+    bf, dev = torch.bfloat16, torch.device(DEV)
+    wp = conv.weight.detach().permute(0, 2, 3, 1).reshape(K, -1).contiguous().to(DEV, bf)
+    xa = Act.of(nhwc(x.detach()).to(bf))
+    z, u = Act.of(torch.empty(N, H, W, K, dtype=bf, device=DEV)), Act.of(torch.empty(N, H, W, K, dtype=bf, device=DEV))
+    bn_dev = copy.deepcopy(bn).to(DEV)
+    bn_dev.running_mean.zero_(); bn_dev.running_var.fill_(1.0)
+    p = Plan(dev)
+    p.conv(xa, wp, z, R=3, S=3, pad=1)
+    p.bn_train(z, u, bn_dev, L.ACT_NONE)
+    run(p)
+    var = z.buf.float().var(dim=(0, 1, 2), unbiased=False)                      # the batch variance the forward kernel used
+    du = B.act_backward(Act.of(nhwc(dy).to(bf)), u, L.ACT_SILU)
+    dz, dg, db = B.batchnorm_train_backward(du, u, bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), var, bn.eps)
+    dW = B.conv_wgrad(xa, dz, R=3, S=3, pad=1)
+    dx = Act.of(torch.empty(N, H, W, C, dtype=bf, device=DEV))
+    p2 = Plan(dev)
+    B.conv_dgrad(p2, dz, B.dgrad_weight(wp, 3, 3), dx, R=3, S=3, pad=1)
+    run(p2)
+    close = lambda got, want, tol=4e-2: (got.float().cpu() - want).abs().max().item() <= tol * want.abs().max().item()
+    assert close(dx.buf.permute(0, 3, 1, 2), x.grad)
+    assert close(dW, conv.weight.grad.permute(0, 2, 3, 1).reshape(K, -1))
+    assert close(dg, bn.weight.grad) and close(db, bn.bias.grad)
