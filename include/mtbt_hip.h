@@ -38,6 +38,9 @@ extern "C" {
 #define MTBT_ACT_SILU 1 /* main_model.py:136 ; ultralytics Conv */
 #define MTBT_ACT_ELU 2  /* main_model.py:96 */
 #define MTBT_ACT_GELU 3 /* timm Mlp act (erf form), main_model.py:21-26 [upstream] */
+#define MTBT_ACT_DSILU 5 /* backward epilogues of mtbt_conv2d_nhwc: y = (conv * scale + shift) * act'(res), res = the kept PRE-activation */
+#define MTBT_ACT_DELU 6
+#define MTBT_ACT_DGELU 7 /* e.g. the ConvNeXt fc2 input gradient lands directly as d(fc1 pre-activation) */
 #define MTBT_ACT_GELU_POLY 4 /* the same GELU as x * Phi(x) with Phi an odd degree-13 polynomial on [-4,4]: |error| <= 2.3e-4,
                               below bf16 resolution; no exp / rcp.  For bf16 outputs (the fp32 parity mode uses MTBT_ACT_GELU). */
 
@@ -80,6 +83,8 @@ typedef struct mtbt_conv_args {
   int32_t out_mode;    /* MTBT_OUT_* */
   int32_t tile_hint;   /* 0 = heuristic; else (TC<<16)|TP to force a tile (tests / tuning); bit 25 = row-reuse direct 3x3
                           kernel, bit 26 = keep a 3x3 on the implicit-GEMM kernel, bit 27 = 64-byte K-steps, bits 28-30 = stages */
+  void* y2;            /* optional second output (training forward): the PRE-activation conv * scale + shift, addressed and typed
+                          like y (no residual added); NULL = not written.  MTBT_OUT_NHWC only. */
 } mtbt_conv_args;
 
 int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream);
@@ -126,6 +131,8 @@ typedef struct mtbt_fuse_args {
   int32_t N, H, W, C; /* OUTPUT size; input i has H/2,W/2 (up), 2H,2W (down) or H,W */
   int32_t dtype;
   int32_t add_weight_bug;
+  const float* wgt_dev; /* optional: n_in weights in DEVICE memory used instead of wgt[] (training: the fusion weights are
+                           parameters that change every step, main_model.py:191-196) */
 } mtbt_fuse_args;
 
 int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream);
@@ -304,9 +311,10 @@ int64_t mtbt_seg_confusion_workspace_bytes(int B);
 int mtbt_seg_confusion(const float* logits, const float* gt, int B, int64_t n_per_image, int64_t* counts, float* prob_sum,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Weight gradient of a k x k convolution (any stride / padding; 1x1 and the 2x2 stride-2 downsample included), bf16 operands:
+/* Weight gradient of a k x k convolution (any stride / padding; 1x1 and the 2x2 stride-2 downsample included), bf16 (MFMA) or fp32 operands:
  *   dw[k][r][s][c] (fp32, packed [K][R*S*C] like the forward weight) (+)= sum_p dy[p][k] * x[n][y*stride + r - pad][x*stride + s - pad][c]
- * x [N,H,W,C], dy [N,Ho,Wo,K] (Ho = (H + 2 pad - R) / stride + 1) NHWC with pixel / batch strides in elements (multiples of 8; C % 8 == K % 8 == 0).  accumulate != 0
+ * x [N,H,W,C], dy [N,Ho,Wo,K] (Ho = (H + 2 pad - R) / stride + 1) NHWC with pixel / batch strides in elements (multiples of 8; C % 8 == K % 8 == 0;
+ * fp32 operands -- the parity mode, a VALU kernel -- multiples of 4).  accumulate != 0
  * adds to dw (gradient accumulation into a flat bucket).  Deterministic: per-slice fp32 partials in `workspace`
  * (>= mtbt_conv_wgrad_workspace_bytes) summed in a fixed order.  This is what autograd computes for `Conv2d.weight.grad`. */
 int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S);
@@ -332,7 +340,7 @@ int mtbt_channel_affine2(const void* x1, const void* x2, const float* a, const f
  * optional xhat output) dense [pixels][C], f32 or bf16; w = gamma [C] f32.  dx = rstd (g - mean_c g - xhat mean_c(g xhat)), g = dy gamma.
  * d gamma = mtbt_channel_sum(dy, xhat), d beta = mtbt_channel_sum(dy). */
 int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, void* xhat, int64_t pixels, int C,
-                                 int dtype, void* stream);
+                                 int dtype, int accumulate /* != 0: dx += (dx already holds another consumer's gradient) */, void* stream);
 
 /* Weight gradient of a depthwise k x k convolution (stride 1, pad k/2; k = 3 or 7): dw[tap][c] (fp32, the forward tap layout [k*k][C])
  * (+)= sum_p dy[p][c] * x[p shifted by the tap][c]; x, dy dense [N,H,W,C], f32 or bf16.  Deterministic.  (One pass per filter
@@ -343,9 +351,130 @@ int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, in
 
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.
- * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4. */
+ * step >= 1 is the number of the step being taken (bias corrections use beta^step).  n need not be a multiple of 4.
+ * grad_scale: optional DEVICE scalar multiplied into every gradient first (the clip coefficient, see mtbt_clip_coef). */
 int mtbt_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int64_t step, void* stream);
+                    float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale, void* stream);
+
+/* torch.optim.SGD over a flat fp32 bucket (BASELINE configs[2] names SGD; momentum / dampening / weight decay / Nesterov as torch's
+ * single-tensor form; momentum_buf may be NULL when momentum == 0; step 1 initialises the buffer with the gradient). */
+int mtbt_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                  float weight_decay, int nesterov, int64_t step, const float* grad_scale, void* stream);
+
+/* Gradient clipping by global norm (Trainer(gradient_clip_val=10), running_main_v3.py:826 -> torch.nn.utils.clip_grad_norm_):
+ * mtbt_sumsq adds the sum of squares of one flat bucket to *out (deterministic two-level reduction; workspace >=
+ * mtbt_sumsq_workspace_bytes()); after an all-reduce-free sum over the buckets, mtbt_clip_coef writes
+ * coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)) -- the device scalar the optimiser kernels take as `grad_scale` (NULL = 1),
+ * so clipping costs no pass over the gradients and no host synchronisation. */
+int64_t mtbt_sumsq_workspace_bytes(void);
+int mtbt_sumsq(const float* g, int64_t n, float* out, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+int mtbt_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+
+/* =============================================================================================================================
+ * Training step (BASELINE configs[2]-[3]; running_main_v3.py:393-445 training_step -> total_loss.backward() -> clip -> optimizer).
+ * The entry points below, with mtbt_conv2d_nhwc (dgrad = the forward kernel on dY with re-laid-out weights; y2 / MTBT_ACT_D*),
+ * mtbt_conv_wgrad, mtbt_dwconv_wgrad, mtbt_layernorm_backward_nhwc and mtbt_multitask_loss(_grad), are what the backward plan
+ * of `ConvNeXtBiFPNYOLO.forward(x, "train")` launches (multitask_bonetumor_yolo_amd/train.py).
+ * ============================================================================================================================= */
+
+/* Training variants of the stem and the depthwise kernel: they also write what the backward pass needs.
+ * stem: `raw` [N,H/4,W/4,Cout] (out_dtype) = the LayerNorm2d INPUT (conv + bias).
+ * dwconv, LayerNorm form: `raw` = conv + bias (the LayerNorm input); scale / shift form: `res` is added after the activation and
+ * may alias y -- the depthwise input gradient accumulating into a buffer that already holds the residual branch's gradient. */
+int mtbt_stem_conv4x4_ln_train(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float ln_eps,
+                               void* y, void* raw, int N, int H, int W, int Cout, int out_dtype, void* stream);
+int mtbt_dwconv_nhwc_train(const void* x, const void* w, const float* bias, const float* ln_w, const float* ln_b, float ln_eps,
+                           const float* scale, const float* shift, int act, void* y, void* raw, const void* res, int N, int H, int W,
+                           int C, int ksize, int dtype, void* stream);
+
+/* BatchNorm2d forward, general form (every ConvBlock / DepthwiseConvBlock / ultralytics Conv BatchNorm under model.train(),
+ * main_model.py:95,126-136): x dense [pixels][C]; y rows of y_pixel_stride elements (a channel slice of a C2f concat buffer,
+ * main_model.py:144-173, or dense).  use_running != 0: module in eval mode (running statistics, nothing updated).  stats [2*C]
+ * receives the (mean, biased variance) used -- the input of mtbt_bn_backward_nhwc.  workspace >= mtbt_bn_train_workspace_bytes. */
+int mtbt_bn_forward_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, int use_running,
+                         float* stats, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Backward of activation + BatchNorm2d in one operator: dy = gradient of the ACTIVATED output (rows of dy_pixel_stride elements),
+ * x = the conv output the forward normalised (dense), stats as written by mtbt_bn_forward_nhwc.
+ *   du = dy * act'(xhat * gamma + beta);  d beta (+)= sum du;  d gamma (+)= sum du * xhat;
+ *   dx = gamma * rstd * (du - mean(du) - xhat * mean(du * xhat))     (use_running: dx = gamma * rstd * du)
+ * Two passes over (dy, x), deterministic.  dgamma / dbeta may be NULL. */
+int64_t mtbt_bn_backward_workspace_bytes(int64_t pixels, int C);
+int mtbt_bn_backward_nhwc(const void* dy, int32_t dy_pixel_stride, const void* x, const float* stats, const float* gamma, const float* beta,
+                          float eps, int act, int use_running, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t pixels, int C,
+                          int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Per-step weight preparation, ONE launch for the whole network: descriptor j turns a master parameter (fp32, any strides) into the
+ * dense row-major [dim0][dim1][dim2][dim3] tensor a kernel reads, in the compute dtype:
+ *   dst[a][b][c][d] = src[ia*sstride0 + ib*sstride1 + ic*sstride2 + id*sstride3] * scale0[index of dim scale0_dim] * scale1[...]
+ * with ix = flip[x] ? dim[x]-1-x : x.  Forward weights: KRSC; dgrad weights: C,R,S,K with R,S flipped; ConvNeXt fc2 with the layer
+ * scale, DepthwiseConvBlock with its k=1 depthwise scale: per-row / per-column scale vectors.  table_dev / block_start_dev live in
+ * DEVICE memory; block_start[j] = first workgroup of descriptor j (mtbt_weight_prep_blocks(elements) workgroups each). */
+typedef struct mtbt_prep_desc {
+  const float* src;
+  void* dst;
+  const float* scale0;
+  const float* scale1;
+  int64_t sstride[4];
+  int32_t dim[4];
+  int32_t flip[4];
+  int32_t scale0_dim, scale1_dim;
+  int32_t dst_dtype;
+  int32_t reserved;
+} mtbt_prep_desc;
+int mtbt_weight_prep_blocks(int64_t elements);
+int mtbt_weight_prep(const mtbt_prep_desc* table_dev, const int32_t* block_start_dev, int n_desc, int total_blocks, void* stream);
+
+/* BiFPN fusion weights on the device (main_model.py:194-196): out[i][j] = ELU(w[i][j]) / (sum_i ELU(w[i][j]) + eps), w [n][2]
+ * (n = 2: w1, n = 3: w2), and the backward of that normalisation (dw (+)= J^T dout). */
+int mtbt_bifpn_norm_weights(const float* w, int n, float eps, float* out, void* stream);
+int mtbt_bifpn_norm_weights_backward(const float* w, int n, float eps, const float* dout, float* dw, int accumulate, void* stream);
+
+/* One input of a BiFPN fusion node y = sum_i w_i * resample_i(x_i) (main_model.py:211-240), backward:
+ *   dx (+)= wgt * resample^T(dy);   *dwgt (+)= <dy, resample(x_in)>
+ * dy [N,H,W,C]; x_in / dx [N,H,W,C] (mode 0), [N,H/2,W/2,C] (mode 1, bilinear x2) or [N,2H,2W,C] (mode 2, 2x2 mean); wgt, dwgt DEVICE
+ * scalars; dx or dwgt may be NULL.  Dense NHWC in `dtype`; workspace >= mtbt_bifpn_fuse_backward_workspace_bytes(). */
+int64_t mtbt_bifpn_fuse_backward_workspace_bytes(void);
+int mtbt_bifpn_fuse_backward(const void* dy, const void* x_in, int mode, const float* wgt, void* dx, int accumulate_dx, float* dwgt,
+                             int accumulate_dwgt, int N, int H, int W, int C, int dtype, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+
+/* Backward of the trainer's proto projector + bilinear resize (running_main_v3.py:251-255): dseg [N,Hout,Wout] f32 = d loss / d (resized
+ * logits); protos [N,hp,wp,nm] f32 (forward output); w [nm] the Conv2d(nm,1,1) weight.  d_protos [N,hp,wp,nm] (dprotos_dtype) (+)=;
+ * dw [nm], db [1] fp32 (+)= (dw NULL to skip both). */
+int64_t mtbt_projector_backward_workspace_bytes(int N, int hp, int wp, int nm);
+int mtbt_projector_backward(const float* dseg, const float* protos, const float* w, void* d_protos, int dprotos_dtype, int accumulate_dprotos,
+                            float* dw, float* db, int accumulate_dw, int N, int hp, int wp, int nm, int Hout, int Wout, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+
+/* AdaptiveAvgPool2d(1) + Linear backward (main_model.py:333-334, :364): x [N,HW,C]; dlogits [N,nout]; w [nout][C];
+ * dx (+)= (W^T dlogits) / HW broadcast over the pixels; dw [nout][C] (+)= dlogits^T pool; db [nout] (+)= sum_n dlogits (may be NULL).
+ * pool_ws: [N][C] floats of scratch. */
+int mtbt_gap_fc_backward(const void* x, const float* dlogits, const float* w, void* dx, int accumulate_dx, float* dw, float* db,
+                         int accumulate_dw, float* pool_ws, int N, int HW, int C, int nout, int dtype, void* stream);
+
+/* dst[n][p][c] = c < C ? src[n][p][c] : 0, c < C_pad, with dtype conversion; element strides, no alignment requirement (the fp32
+ * Detect gradient maps are 66 floats wide: their 64- and nc-channel slices become dense, zero-padded operands of dgrad / wgrad). */
+int mtbt_copy_strided(const void* src, int src_dtype, int64_t src_batch_stride, int32_t src_pixel_stride, void* dst, int dst_dtype,
+                      int64_t dst_batch_stride, int32_t dst_pixel_stride, int N, int64_t pixels, int C, int C_pad, void* stream);
+
+/* Parameter gradients of a weight the forward folded with a vector, from the raw GEMM weight gradient G [K][C] (fp32, dense):
+ *   mode 0, rows (ConvNeXt y = x + gamma * (W h + b), timm layer scale): dW (+)= gamma[k] G;  dvec = d gamma[k] (+)= sum_c W G + bias[k] s[k];
+ *           dbias[k] (+)= gamma[k] s[k], with s[k] = sum_p dy[p][k]  (bias / s / dbias may be NULL)
+ *   mode 1, columns (DepthwiseConvBlock y = W (v * x), main_model.py:84-93): dW (+)= G v[c];  dvec = d v[c] (+)= sum_k G W. */
+int mtbt_scale_grad(int mode, const float* G, const float* W, const float* vec, const float* bias, const float* s, float* dW, float* dvec,
+                    float* dbias, int K, int C, int accumulate, void* stream);
+
+/* dst += src over [N][pixels][C] views (element strides, multiples of 8): gradient accumulation where the producer cannot. */
+int mtbt_add_nhwc(void* dst, int64_t dst_batch_stride, int32_t dst_pixel_stride, const void* src, int64_t src_batch_stride,
+                  int32_t src_pixel_stride, int N, int64_t pixels, int C, int dtype, void* stream);
+
+/* Weight gradient of the ConvNeXt stem conv (4x4, stride 4, 3 -> K) on the caller's NCHW fp32 image: dw [K][48] (torch's [K,3,4,4])
+ * (+)= sum_p d[p][k] * patch(p); d dense [N*(H/4)*(W/4)][K] in `dtype`. */
+int64_t mtbt_stem_wgrad_workspace_bytes(int K);
+int mtbt_stem_wgrad(const float* x, const void* d, float* dw, int N, int H, int W, int K, int dtype, int accumulate, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* dtype / layout helpers on the boundary */
 int mtbt_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);

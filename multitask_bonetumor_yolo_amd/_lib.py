@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY, ACT_DSILU, ACT_DELU, ACT_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
 OUT_NHWC, OUT_CONVT2X2 = 0, 1
 RES_ID, RES_UP_BILINEAR, RES_DOWN_MEAN, RES_UP_NEAREST, RES_MAXPOOL = 0, 1, 2, 3, 4
 
@@ -23,7 +23,7 @@ class ConvArgs(C.Structure):
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("K", C.c_int32),
         ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32),
-        ("act", C.c_int32), ("out_mode", C.c_int32), ("tile_hint", C.c_int32),
+        ("act", C.c_int32), ("out_mode", C.c_int32), ("tile_hint", C.c_int32), ("y2", C.c_void_p),
     ]
 
 
@@ -31,7 +31,7 @@ class FuseArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p * 3), ("wgt", C.c_float * 3), ("resample", C.c_int32 * 3), ("n_in", C.c_int32),
         ("y", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-        ("dtype", C.c_int32), ("add_weight_bug", C.c_int32),
+        ("dtype", C.c_int32), ("add_weight_bug", C.c_int32), ("wgt_dev", C.c_void_p),
     ]
 
 
@@ -69,6 +69,12 @@ class LossArgs(C.Structure):
 
 
 # every symbol include/mtbt_hip.h declares: name -> (restype, argtypes)
+class PrepDesc(C.Structure):  # mtbt_prep_desc
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale0", C.c_void_p), ("scale1", C.c_void_p),
+                ("sstride", C.c_int64 * 4), ("dim", C.c_int32 * 4), ("flip", C.c_int32 * 4),
+                ("scale0_dim", C.c_int32), ("scale1_dim", C.c_int32), ("dst_dtype", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RawImage(C.Structure):  # mtbt_raw_image
     _fields_ = [("bgr", C.c_void_p), ("mask", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32),
                 ("row_stride", C.c_int64), ("mask_row_stride", C.c_int64)]
@@ -108,10 +114,39 @@ SYMBOLS = {
     "mtbt_channel_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "mtbt_channel_affine2": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "mtbt_layernorm_backward_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_layernorm_backward_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_dwconv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 5),
     "mtbt_dwconv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_int64, C.c_void_p]),
-    "mtbt_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_void_p]),
+    "mtbt_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    "mtbt_sgd_step": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mtbt_sumsq_workspace_bytes": (C.c_int64, []),
+    "mtbt_sumsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_clip_coef": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtbt_stem_conv4x4_ln_train": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "mtbt_dwconv_nhwc_train": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                               + [C.c_int] * 6 + [C.c_void_p]),
+    "mtbt_bn_forward_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_bn_backward_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "mtbt_bn_backward_nhwc": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 3
+                              + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_weight_prep_blocks": (C.c_int, [C.c_int64]),
+    "mtbt_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_bifpn_norm_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "mtbt_bifpn_norm_weights_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mtbt_bifpn_fuse_backward_workspace_bytes": (C.c_int64, []),
+    "mtbt_bifpn_fuse_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5
+                                 + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_projector_backward_workspace_bytes": (C.c_int64, [C.c_int] * 4),
+    "mtbt_projector_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 6
+                                + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_gap_fc_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "mtbt_copy_strided": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int64,
+                                    C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_scale_grad": (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_add_nhwc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_stem_wgrad_workspace_bytes": (C.c_int64, [C.c_int]),
+    "mtbt_stem_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 

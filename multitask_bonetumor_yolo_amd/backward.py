@@ -137,7 +137,7 @@ def layernorm_backward(x: Act, dy: Act, gamma: torch.Tensor, eps: float):
     dev = x.buf.device
     dx, xhat = Act.of(torch.empty_like(x.buf)), Act.of(torch.empty_like(x.buf))
     g = gamma.float().contiguous()
-    L.check(lib.mtbt_layernorm_backward_nhwc(x.ptr, dy.ptr, g.data_ptr(), eps, dx.ptr, xhat.ptr, x.N * x.H * x.W, x.C, x.code,
+    L.check(lib.mtbt_layernorm_backward_nhwc(x.ptr, dy.ptr, g.data_ptr(), eps, dx.ptr, xhat.ptr, x.N * x.H * x.W, x.C, x.code, 0,
                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mtbt_layernorm_backward_nhwc")
     dx._keep = g
     return dx, channel_sum(dy, times=xhat), channel_sum(dy)

@@ -65,11 +65,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblock
 
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ var,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act, long pixels, int C) {
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act, long pixels, int C,
+                                int y_ld) {
   const int CH8 = C >> 3;
   const long total = pixels * CH8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cg = (int)(i % CH8);
+    const long pix = i / CH8;
     float v[8], mu[8], va[8], ga[8], be[8];
     ld8<T>(x + i * 8, v);
     ld8<float>(mean + cg * 8, mu);
@@ -78,8 +80,13 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
     ld8<float>(beta + cg * 8, be);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_apply((v[e] - mu[e]) * rsqrtf(va[e] + eps) * ga[e] + be[e], act);
-    st8<T>(y + i * 8, v);
+    st8<T>(y + pix * y_ld + cg * 8, v);
   }
+}
+
+__global__ void bn_copy_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mean, float* __restrict__ var, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { mean[c] = rm[c]; var[c] = rv[c]; }
 }
 
 }  // namespace
@@ -90,40 +97,61 @@ extern "C" int64_t mtbt_bn_train_workspace_bytes(int64_t pixels, int C) {
   return (nb * C + 2 * (int64_t)C) * (int64_t)sizeof(float);
 }
 
+// General form (training lowering): x dense [pixels][C]; y rows of y_pixel_stride elements (a channel slice of a C2f concat buffer, or
+// dense; may alias x when dense).  use_running != 0: normalise with running_mean / running_var (module in eval mode; nothing is updated).
+// stats [2*C] receives the (mean, biased variance) the normalisation used -- what mtbt_bn_backward_nhwc reads.
+extern "C" int mtbt_bn_forward_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, int use_running,
+                                    float* stats, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !y || !gamma || !beta || !stats || pixels <= 0 || C <= 0 || C % 8 || C > 2048 || y_pixel_stride < C || y_pixel_stride % 8) return MTBT_EINVAL;
+  if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
+  if (act < MTBT_ACT_NONE || act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || !aligned16(stats)) return MTBT_EALIGN;
+  if (use_running && (!running_mean || !running_var)) return MTBT_EINVAL;
+  const long nb = (pixels + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (nb > 0x7fffffffL) return MTBT_EINVAL;
+  const int CH8 = C / 8;
+  if (CH8 > 256) return MTBT_EINVAL;
+  float* mean = stats;
+  float* var = stats + C;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned fb = (unsigned)((C + 255) / 256);
+  const long total = pixels * CH8;
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (use_running) {
+    hipLaunchKernelGGL(bn_copy_stats_kernel, dim3(fb), dim3(256), 0, s, running_mean, running_var, mean, var, C);
+  } else {
+    if (!workspace || !aligned16(workspace)) return MTBT_EALIGN;
+    if (workspace_bytes < nb * C * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+    float* partial = reinterpret_cast<float*>(workspace);
+    const size_t lds = (size_t)(256 / CH8) * C * sizeof(float);
+#define BN_STATS(T)                                                                                                            \
+    hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x, (long)pixels, C, nullptr, partial); \
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fb), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, nullptr, nullptr, 0.f); \
+    hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x, (long)pixels, C, mean, partial);   \
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fb), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, running_mean,   \
+                       running_var, momentum);
+    if (dtype == MTBT_F32) { BN_STATS(float) } else { BN_STATS(bf16_t) }
+#undef BN_STATS
+  }
+  if (dtype == MTBT_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
 // x, y: dense NHWC [pixels][C] in `dtype` (y may alias x).  gamma/beta/running_*: fp32 [C] (running_* may be NULL).
 // workspace: >= mtbt_bn_train_workspace_bytes; on return its last 2*C floats hold the batch mean and biased variance.
 extern "C" int mtbt_bn_train_nhwc(const void* x, void* y, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype,
                                   void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!x || !y || !gamma || !beta || !workspace || pixels <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
-  if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
-  if (!aligned16(x) || !aligned16(y) || !aligned16(workspace) || !aligned16(gamma) || !aligned16(beta)) return MTBT_EALIGN;
+  if (!workspace || pixels <= 0 || C <= 0) return MTBT_EINVAL;
   if (workspace_bytes < mtbt_bn_train_workspace_bytes(pixels, C)) return MTBT_EWORKSPACE;
   const long nb = (pixels + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  if (nb > 0x7fffffffL) return MTBT_EINVAL;
-  float* partial = reinterpret_cast<float*>(workspace);
-  float* mean = partial + nb * C;
-  float* var = mean + C;
-  const int CH8 = C / 8;
-  if (CH8 > 256) return MTBT_EINVAL;
-  const size_t lds = (size_t)(256 / CH8) * C * sizeof(float);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const unsigned fb = (unsigned)((C + 255) / 256);
-#define BN_RUN(T)                                                                                                              \
-  hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x, (long)pixels, C, nullptr, partial); \
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fb), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, nullptr, nullptr, 0.f); \
-  hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x, (long)pixels, C, mean, partial);   \
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fb), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, running_mean,   \
-                     running_var, momentum);                                                                                      \
-  {                                                                                                                              \
-    const long total = pixels * CH8;                                                                                             \
-    long g = (total + 255) / 256;                                                                                                \
-    if (g > 8192) g = 8192;                                                                                                      \
-    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3((unsigned)g), dim3(256), 0, s, (const T*)x, (T*)y, mean, var, gamma, beta, eps, act,   \
-                       (long)pixels, C);                                                                                        \
-  }
-  if (dtype == MTBT_F32) { BN_RUN(float) } else { BN_RUN(bf16_t) }
-#undef BN_RUN
-  MTBT_LAUNCH_CHECK();
-  return MTBT_OK;
+  float* stats = reinterpret_cast<float*>(workspace) + nb * C;
+  return mtbt_bn_forward_nhwc(x, y, C, gamma, beta, running_mean, running_var, momentum, eps, act, pixels, C, dtype, 0, stats, workspace,
+                              workspace_bytes, stream);
 }

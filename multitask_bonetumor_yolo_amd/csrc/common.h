@@ -96,6 +96,16 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// Derivative of the epilogue activations at the PRE-activation z (backward pass): dz = dy * act_grad(z).  Codes 5..7 are the
+// "multiply by act'(res)" epilogue modes of the conv kernel (MTBT_ACT_DSILU / DELU / DGELU).
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == MTBT_ACT_SILU || act == MTBT_ACT_DSILU) { const float s = fast_rcp(1.f + fast_exp(-z)); return s * (1.f + z * (1.f - s)); }
+  if (act == MTBT_ACT_ELU || act == MTBT_ACT_DELU) return z > 0.f ? 1.f : fast_exp(z);
+  if (act == MTBT_ACT_GELU || act == MTBT_ACT_GELU_POLY || act == MTBT_ACT_DGELU)
+    return 0.5f * (1.f + fast_erf(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * fast_exp(-0.5f * z * z);
+  return 1.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -2,10 +2,12 @@
 //
 // Accumulator layout (16x16 MFMA, rows = channels): lane (lr = lane&15, lq = lane>>4) holds, per fragment
 // (i, j), channels 16 i + 4 lq .. +3 of pixel 16 j + lr.  Per 16-pixel slab j:
-//   (1) affine (+ activation) in fp32 and a float4 store into the wave's [16 px][WCH ch] fp32 LDS slab
+//   (1) affine in fp32 and a float4 store into the wave's [16 px][WCH ch] fp32 LDS slab
 //       (row pitch +16 B: conflict-free b128 writes); scale/shift come from a per-workgroup LDS copy;
 //   (2) lanes re-read the slab as rows: 8 consecutive channels of one pixel per lane (two ds_read_b128),
-//       add the residual (one 16-byte load) and issue ONE 16-byte (bf16) / two 16-byte (f32) coalesced stores.
+//       optionally store them as the pre-activation (y2, training forward), apply the activation, add the residual (one
+//       16-byte load) -- or, in the backward modes MTBT_ACT_D*, multiply by act'(residual) -- and issue ONE 16-byte (bf16) /
+//       two 16-byte (f32) coalesced stores.
 // The caller guarantees the main loop is over (barrier) before the slabs are written.
 // (Measured alternative: 8-byte stores straight from the accumulators, no LDS pass -- 3.5 % SLOWER over the network's
 // convs, although the same idea wins in mlp_fused.hip where the slab form needed four passes of 12-piece rows.)
@@ -47,8 +49,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
         const float4 sc = *reinterpret_cast<const float4*>(aff + cl);
         v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
       }
-      v.x = act_apply(v.x + sh.x, p.act); v.y = act_apply(v.y + sh.y, p.act);
-      v.z = act_apply(v.z + sh.z, p.act); v.w = act_apply(v.w + sh.w, p.act);
+      v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;   // the activation is applied in pass (2), where the row form also feeds y2
       *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
     }
     // wave-local hand-off through LDS (other lanes' data): a compiler barrier is REQUIRED -- the float4 row reads
@@ -65,12 +66,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       const float4 lo = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32);
       const float4 hi = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32 + 16);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const bool deriv = p.act >= MTBT_ACT_DSILU;   // backward epilogue: multiply by act'(res) instead of act() + res
       if (p.vec_ok && ch + 8 <= p.K) {
+        if (p.y2) {   // training forward: keep the pre-activation next to the activated output
+          if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y2) + yoff, v);
+          else st8<bf16_t>(reinterpret_cast<bf16_t*>(p.y2) + yoff, v);
+        }
+        if (!deriv) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], p.act);
+        }
         if (p.res) {
           float r[8];
           ld8<T>(reinterpret_cast<const T*>(p.res) + roff, r);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += r[e];
+          for (int e = 0; e < 8; ++e) v[e] = deriv ? v[e] * act_grad(r[e], p.act) : v[e] + r[e];
         }
         if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y) + yoff, v);
         else st8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + yoff, v);
@@ -79,7 +89,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
         const int lim = (p.out_mode == MTBT_OUT_CONVT2X2) ? (ch / (p.K >> 2) + 1) * (p.K >> 2) : p.K;
         for (int e = 0; e < 8 && ch + e < lim; ++e) {
           float u = v[e];
-          if (p.res) u += ld_elem<T>(reinterpret_cast<const T*>(p.res) + roff + e);
+          if (p.y2) {
+            if (p.out_f32) reinterpret_cast<float*>(p.y2)[yoff + e] = u;
+            else reinterpret_cast<bf16_t*>(p.y2)[yoff + e] = f2bf(u);
+          }
+          if (!deriv) u = act_apply(u, p.act);
+          if (p.res) {
+            const float r = ld_elem<T>(reinterpret_cast<const T*>(p.res) + roff + e);
+            u = deriv ? u * act_grad(r, p.act) : u + r;
+          }
           if (p.out_f32) reinterpret_cast<float*>(p.y)[yoff + e] = u;
           else reinterpret_cast<bf16_t*>(p.y)[yoff + e] = f2bf(u);
         }

@@ -71,12 +71,14 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   if (a->Ho != (a->H + 2 * a->pad - a->R) / a->stride + 1 || a->Wo != (a->W + 2 * a->pad - a->S) / a->stride + 1) return MTBT_EINVAL;
   if (a->out_mode != MTBT_OUT_NHWC && a->out_mode != MTBT_OUT_CONVT2X2) return MTBT_EINVAL;
   if (a->out_mode == MTBT_OUT_CONVT2X2 && (a->K % 4 != 0)) return MTBT_EINVAL;
-  if (a->act < 0 || a->act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
+  if (a->act < 0 || a->act > MTBT_ACT_DGELU) return MTBT_EINVAL;
+  if (a->act >= MTBT_ACT_DSILU && !a->res) return MTBT_EINVAL;  // the derivative epilogues read the pre-activation through res
+  if (a->y2 && (a->out_mode != MTBT_OUT_NHWC || !aligned16(a->y2))) return MTBT_EINVAL;
   if (!aligned16(a->x) || !aligned16(a->w) || a->x_pixel_stride % epc != 0 || a->x_batch_stride % epc != 0) return MTBT_EALIGN;
   if (a->x_pixel_stride < a->C) return MTBT_EINVAL;
 
   ConvP p;
-  p.x = a->x; p.w = a->w; p.y = a->y; p.scale = a->scale; p.shift = a->shift; p.res = a->res;
+  p.x = a->x; p.w = a->w; p.y = a->y; p.scale = a->scale; p.shift = a->shift; p.res = a->res; p.y2 = a->y2;
   p.xbs = a->x_batch_stride; p.ybs = a->y_batch_stride; p.rbs = a->res_batch_stride;
   p.ldx = a->x_pixel_stride; p.ldy = a->y_pixel_stride; p.ldr = a->res_pixel_stride;
   p.N = a->N; p.H = a->H; p.W = a->W; p.C = a->C; p.K = a->K; p.R = a->R; p.S = a->S;

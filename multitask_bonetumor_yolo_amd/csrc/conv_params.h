@@ -8,6 +8,7 @@ struct ConvP {
   const float* scale;
   const float* shift;
   const void* res;
+  void* y2;  // optional pre-activation output, addressed like y
   long xbs, ybs, rbs;
   int ldx, ldy, ldr;
   int N, H, W, C, K, R, S, stride, pad, Ho, Wo;

@@ -77,7 +77,8 @@ template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB>
 __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
     const T* __restrict__ x, const T* __restrict__ w /* [KS*KS][C] */, const float* __restrict__ bias,
     const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, const float* __restrict__ scale,
-    const float* __restrict__ shift, int act, T* __restrict__ y, int N, int H, int W, int C, int dbg) {
+    const float* __restrict__ shift, int act, T* __restrict__ y, T* __restrict__ raw, const T* res, int N, int H, int W,
+    int C, int dbg) {
   constexpr int PAD = KS / 2, YB = 2, SPAN = XB + KS - 1, ROWS = YB + KS - 1;
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
   constexpr int ES = (int)sizeof(T), PIXB = CC * ES;  // bytes per staged pixel
@@ -269,6 +270,24 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
             }
         }
       }
+      if (raw) {   // training forward: keep the LayerNorm input (conv + bias) for the LayerNorm backward
+        T* rt = raw + (((long)n * H + oy0) * W + ox0) * C;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+          const int c0 = k * CC + lane * 2;
+          if (k < nchunks && c0 < C) {
+#pragma unroll
+            for (int a = 0; a < YB; ++a) {
+              if (oy0 + a >= H) continue;
+#pragma unroll
+              for (int i = 0; i < XB; ++i) {
+                if (ox0 + i >= W) continue;
+                Pair<T>::st(rt + (a * rowel + (unsigned)(i * C + c0)), acc[k][a][i]);
+              }
+            }
+          }
+        }
+      }
       wave_sum16(s, red, lane);
       const float invC = 1.0f / C;
       float q[16];
@@ -319,7 +338,9 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
             for (int i = 0; i < XB; ++i) {
               if (ox0 + i >= W) continue;
               const f32x2 v = fma2(acc[k][a][i], sc, sh);
-              Pair<T>::st(yt + (a * rowel + (unsigned)(i * C + c0)), f32x2{act_apply(v.x, act), act_apply(v.y, act)});
+              f32x2 o = f32x2{act_apply(v.x, act), act_apply(v.y, act)};
+              if (res) o += Pair<T>::ld(res + (((long)n * H + oy0) * W + ox0) * C + (a * rowel + (unsigned)(i * C + c0)));  // may alias y
+              Pair<T>::st(yt + (a * rowel + (unsigned)(i * C + c0)), o);
             }
           }
         }
@@ -330,7 +351,7 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
 
 template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB = 8>
 int launch_dw(const void* x, const void* w, const float* bias, const float* lnw, const float* lnb, float eps,
-              const float* scale, const float* shift, int act, void* y, int N, int H, int W, int C, hipStream_t s) {
+              const float* scale, const float* shift, int act, void* y, void* raw, const void* res, int N, int H, int W, int C, hipStream_t s) {
   constexpr int NT = (TH / 2) * (TW / XB) * 64;
   constexpr int PARTS = CC * (int)sizeof(T) / 16, PXI = 64 / PARTS, IWP = ((TW + KS - 1 + PXI - 1) / PXI) * PXI;
   constexpr int lds_tile = (TH + KS - 1) * IWP * CC * (int)sizeof(T), lds_red = LN ? (NT / 64) * (16 * 64 + 16) * 4 : 0;
@@ -346,40 +367,41 @@ int launch_dw(const void* x, const void* w, const float* bias, const float* lnw,
   auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH, XB>;
   if (int rc = mtbt_allow_lds(kern, lds)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, (const T*)x, (const T*)w, bias, lnw, lnb, eps, scale, shift,
-                     act, (T*)y, N, H, W, C, dbg_env());
+                     act, (T*)y, (T*)raw, (const T*)res, N, H, W, C, dbg_env());
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
 
 template <typename T, int KS, bool LN, int TH, int TW>
 int dispatch_chunks(const void* x, const void* w, const float* bias, const float* lnw, const float* lnb, float eps,
-                    const float* scale, const float* shift, int act, void* y, int N, int H, int W, int C, hipStream_t s) {
+                    const float* scale, const float* shift, int act, void* y, void* raw, const void* res, int N, int H, int W, int C,
+                    hipStream_t s) {
   // (An earlier separate kernel for two / three chunks -- taps of a chunk in registers, one tile per workgroup -- was
   // 10-25 % faster on those layers but produced wrong LayerNorm outputs in lanes 48-63 when a CU was shared with an MFMA
   // kernel (tools/pair_stress.py; cause not found in its ISA) and was removed: every shape runs this kernel.)
   const int nch = (C + CC - 1) / CC;
-  if (nch <= 1) return launch_dw<T, KS, LN, TH, TW, 1>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
-  if (nch <= 2) return launch_dw<T, KS, LN, TH, TW, 2>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
-  if (nch <= 3) return launch_dw<T, KS, LN, TH, TW, 3>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
-  if (nch <= 6) return launch_dw<T, KS, LN, TH, TW / 2, 6, 4>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, N, H, W, C, s);
+  if (nch <= 1) return launch_dw<T, KS, LN, TH, TW, 1>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, raw, res, N, H, W, C, s);
+  if (nch <= 2) return launch_dw<T, KS, LN, TH, TW, 2>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, raw, res, N, H, W, C, s);
+  if (nch <= 3) return launch_dw<T, KS, LN, TH, TW, 3>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, raw, res, N, H, W, C, s);
+  if (nch <= 6) return launch_dw<T, KS, LN, TH, TW / 2, 6, 4>(x, w, bias, lnw, lnb, eps, scale, shift, act, y, raw, res, N, H, W, C, s);
   return MTBT_EINVAL;
 }
 
 }  // namespace
 
 // w: [k*k][C] in the activation dtype (bf16 taps in bf16 mode, like every other conv's weights).
-extern "C" int mtbt_dwconv_nhwc(const void* x, const void* w, const float* bias, const float* ln_w, const float* ln_b,
-                                float ln_eps, const float* scale, const float* shift, int act, void* y, int N, int H,
-                                int W, int C, int ksize, int dtype, void* stream) {
+static int dwconv_entry(const void* x, const void* w, const float* bias, const float* ln_w, const float* ln_b, float ln_eps, const float* scale,
+                        const float* shift, int act, void* y, void* raw, const void* res, int N, int H, int W, int C, int ksize, int dtype,
+                        void* stream) {
   if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C > 768) return MTBT_EINVAL;
   if (ksize != 3 && ksize != 7) return MTBT_EINVAL;
   const bool ln = ln_w != nullptr;
-  if (ln && (!ln_b || !bias)) return MTBT_EINVAL;
-  if (!ln && (!scale || !shift)) return MTBT_EINVAL;
-  if (!aligned16(x) || !aligned16(y) || !aligned16(w)) return MTBT_EALIGN;
+  if (ln && (!ln_b || !bias || res)) return MTBT_EINVAL;
+  if (!ln && (!scale || !shift || raw)) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(w) || (raw && !aligned16(raw)) || (res && !aligned16(res))) return MTBT_EALIGN;
   if ((long)(W + 64) * C * 4 >= 0x7fff0000L || (long)H * W * C >= 0x7fff0000L) return MTBT_EINVAL;  // 32-bit offsets in a row / an image
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define DW_ARGS x, w, bias, ln_w, ln_b, ln_eps, scale, shift, act, y, N, H, W, C, s
+#define DW_ARGS x, w, bias, ln_w, ln_b, ln_eps, scale, shift, act, y, raw, res, N, H, W, C, s
   if (dtype == MTBT_BF16) {
     if (ksize == 7) return ln ? dispatch_chunks<bf16_t, 7, true, 4, 16>(DW_ARGS) : dispatch_chunks<bf16_t, 7, false, 4, 16>(DW_ARGS);
     return ln ? dispatch_chunks<bf16_t, 3, true, 4, 16>(DW_ARGS) : dispatch_chunks<bf16_t, 3, false, 4, 16>(DW_ARGS);
@@ -389,4 +411,18 @@ extern "C" int mtbt_dwconv_nhwc(const void* x, const void* w, const float* bias,
   }
 #undef DW_ARGS
   return MTBT_EINVAL;
+}
+
+extern "C" int mtbt_dwconv_nhwc(const void* x, const void* w, const float* bias, const float* ln_w, const float* ln_b,
+                                float ln_eps, const float* scale, const float* shift, int act, void* y, int N, int H,
+                                int W, int C, int ksize, int dtype, void* stream) {
+  return dwconv_entry(x, w, bias, ln_w, ln_b, ln_eps, scale, shift, act, y, nullptr, nullptr, N, H, W, C, ksize, dtype, stream);
+}
+
+// Training variants: `raw` (LayerNorm form only) also receives the LayerNorm INPUT conv + bias (what the LayerNorm backward needs);
+// `res` (scale / shift form only) is added after the activation and may alias y (gradient accumulation of the depthwise dgrad).
+extern "C" int mtbt_dwconv_nhwc_train(const void* x, const void* w, const float* bias, const float* ln_w, const float* ln_b,
+                                      float ln_eps, const float* scale, const float* shift, int act, void* y, void* raw, const void* res,
+                                      int N, int H, int W, int C, int ksize, int dtype, void* stream) {
+  return dwconv_entry(x, w, bias, ln_w, ln_b, ln_eps, scale, shift, act, y, raw, res, N, H, W, C, ksize, dtype, stream);
 }

@@ -12,7 +12,7 @@ namespace {
 template <typename OT, int PIX>
 __global__ void stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                             const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, OT* __restrict__ y,
-                            int N, int H, int W, int Cout, int G) {
+                            OT* __restrict__ raw, int N, int H, int W, int Cout, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* patch = reinterpret_cast<float*>(smem);            // [PIX][48]
   float* outv = patch + PIX * 48;                            // [PIX][Cout]
@@ -62,6 +62,7 @@ __global__ void stem_kernel(const float* __restrict__ x, const float* __restrict
       for (int c = lane; c < Cout; c += 64) { const float d = o[c] - mean; q += d * d; }
       const float rstd = rsqrtf(wave_sum(q) / Cout + eps);
       for (int c = lane; c < Cout; c += 64) st_elem<OT>(y + gp * Cout + c, (o[c] - mean) * rstd * lnw[c] + lnb[c]);
+      if (raw) for (int c = lane; c < Cout; c += 64) st_elem<OT>(raw + gp * Cout + c, o[c]);   // training: the LayerNorm input
     }
     __syncthreads();
   }
@@ -79,7 +80,7 @@ template <int FCH>  // Cout / 16
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, float eps, bf16_t* __restrict__ y,
-                                                        int N, int H, int W) {
+                                                        bf16_t* __restrict__ raw, int N, int H, int W) {
   constexpr int Cout = FCH * 16;
   const int lane = threadIdx.x & 63, nq = lane & 15, q = lane >> 4;
   const int Ho = H >> 2, Wo = W >> 2;
@@ -136,6 +137,16 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     const float rstd = rsqrtf(v * (1.0f / Cout) + eps);
+    if (raw) {   // training: the LayerNorm input
+      bf16_t* ro = raw + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
+#pragma unroll
+      for (int f = 0; f < FCH; ++f) {
+        uint2 o;
+        o.x = (uint32_t)f2bf(acc[f][0]) | ((uint32_t)f2bf(acc[f][1]) << 16);
+        o.y = (uint32_t)f2bf(acc[f][2]) | ((uint32_t)f2bf(acc[f][3]) << 16);
+        *reinterpret_cast<uint2*>(ro + f * 16) = o;
+      }
+    }
     bf16_t* yo = y + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
 #pragma unroll
     for (int f = 0; f < FCH; ++f) {
@@ -207,7 +218,7 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const float* __restric
 // and optionally store xhat (for d gamma = sum_pixels dy * xhat through mtbt_channel_sum; d beta = sum_pixels dy).
 template <typename T, int MAXV, int LP>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w, float eps,
-                                     T* __restrict__ dx, T* __restrict__ xhat, long pixels, int C) {
+                                     T* __restrict__ dx, T* __restrict__ xhat, long pixels, int C, int accumulate) {
   constexpr int PPW = 64 / LP;
   const int lane = threadIdx.x & 63, gl = lane % LP;
   const long pix = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PPW + lane / LP;
@@ -260,6 +271,12 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restric
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - v[i][e] * m2);
+      if (accumulate) {   // dx already holds another consumer's gradient (a ConvNeXt stage output feeds the next stage AND its adaptor)
+        float old[8];
+        ld8<T>(dx + pix * C + ch * 8, old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += old[e];
+      }
       st8<T>(dx + pix * C + ch * 8, o);
       if (xhat) st8<T>(xhat + pix * C + ch * 8, v[i]);
     }
@@ -279,6 +296,7 @@ struct FuseP {
   void* y;
   int N, H, W, C;
   int bug;
+  const float* wgt_dev;  // non-null: the weights are read from device memory (training: they are parameters)
 };
 
 template <typename T>
@@ -334,9 +352,10 @@ __global__ void fuse_kernel(const FuseP p) {
     for (int i = 0; i < 3; ++i) {
       if (i >= p.n_in) break;
       fuse_fetch<T>(reinterpret_cast<const T*>(p.x[i]), p.resample[i], n, y, x, p.H, p.W, p.C, chunk * 8, t);
+      const float wi = p.wgt_dev ? p.wgt_dev[i] : p.wgt[i];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float term = p.bug ? (p.wgt[i] + t[e]) : (p.wgt[i] * t[e]);
+        const float term = p.bug ? (wi + t[e]) : (wi * t[e]);
         acc[e] = (i == 0) ? term : acc[e] + term;
       }
     }
@@ -393,8 +412,8 @@ inline unsigned grid_for(long work, int block) {
 
 }  // namespace
 
-extern "C" int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
-                                    float ln_eps, void* y, int N, int H, int W, int Cout, int out_dtype, void* stream) {
+static int stem_entry(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b, float ln_eps, void* y, void* raw,
+                      int N, int H, int W, int Cout, int out_dtype, void* stream) {
   if (!x || !w || !ln_w || !ln_b || !y || N <= 0 || H % 4 || W % 4 || H <= 0 || W <= 0) return MTBT_EINVAL;
   if (Cout <= 0 || Cout > 512 || Cout % 32) return MTBT_EINVAL;
   if (!aligned16(x)) return MTBT_EALIGN;
@@ -406,20 +425,32 @@ extern "C" int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float*
   const size_t lds = (size_t)PIX * (48 + Cout) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (out_dtype == MTBT_BF16 && Cout == 96 && (W / 4) % 16 == 0 && bias && aligned16(w) && aligned16(bias) && aligned16(ln_w) &&
-      aligned16(ln_b) && aligned16(y)) {
+      aligned16(ln_b) && aligned16(y) && aligned16(raw)) {
     const long groups = (long)N * (H / 4) * (W / 64);
     const unsigned nb = (unsigned)((groups + 3) / 4 > 2048 ? 2048 : (groups + 3) / 4);
-    hipLaunchKernelGGL((stem_mfma_kernel<6>), dim3(nb), dim3(256), 0, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, N, H, W);
+    hipLaunchKernelGGL((stem_mfma_kernel<6>), dim3(nb), dim3(256), 0, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, (bf16_t*)raw, N, H, W);
     MTBT_LAUNCH_CHECK();
     return MTBT_OK;
   }
   if (out_dtype == MTBT_F32)
-    hipLaunchKernelGGL((stem_kernel<float, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (float*)y, N, H, W, Cout, G);
+    hipLaunchKernelGGL((stem_kernel<float, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (float*)y, (float*)raw, N, H, W, Cout, G);
   else if (out_dtype == MTBT_BF16)
-    hipLaunchKernelGGL((stem_kernel<bf16_t, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, N, H, W, Cout, G);
+    hipLaunchKernelGGL((stem_kernel<bf16_t, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, (bf16_t*)raw, N, H, W, Cout, G);
   else return MTBT_EINVAL;
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
+}
+
+extern "C" int mtbt_stem_conv4x4_ln(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                    float ln_eps, void* y, int N, int H, int W, int Cout, int out_dtype, void* stream) {
+  return stem_entry(x, w, bias, ln_w, ln_b, ln_eps, y, nullptr, N, H, W, Cout, out_dtype, stream);
+}
+
+// Training variant: `raw` [N,H/4,W/4,Cout] (out_dtype) also receives the LayerNorm2d INPUT (conv + bias).
+extern "C" int mtbt_stem_conv4x4_ln_train(const float* x, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                                          float ln_eps, void* y, void* raw, int N, int H, int W, int Cout, int out_dtype, void* stream) {
+  if (!raw) return MTBT_EINVAL;
+  return stem_entry(x, w, bias, ln_w, ln_b, ln_eps, y, raw, N, H, W, Cout, out_dtype, stream);
 }
 
 extern "C" int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b, float eps, void* y, int64_t pixels,
@@ -446,7 +477,7 @@ extern "C" int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b
 }
 
 extern "C" int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, void* xhat, int64_t pixels, int C,
-                                            int dtype, void* stream) {
+                                            int dtype, int accumulate, void* stream) {
   if (!x || !dy || !w || !dx || pixels <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (xhat && !aligned16(xhat))) return MTBT_EALIGN;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -456,7 +487,7 @@ extern "C" int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
 #define LNB_LAUNCH(T, MAXV, LPV) \
   hipLaunchKernelGGL((layernorm_bwd_kernel<T, MAXV, LPV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, w, eps, (T*)dx, (T*)xhat, \
-                     (long)pixels, C)
+                     (long)pixels, C, accumulate)
 #define LNB_BY_C(T) \
   do { if (LP == 16) LNB_LAUNCH(T, 1, 16); else if (LP == 32) LNB_LAUNCH(T, 1, 32); else if (CH8 <= 64) LNB_LAUNCH(T, 1, 64); \
        else if (CH8 <= 128) LNB_LAUNCH(T, 2, 64); else LNB_LAUNCH(T, 4, 64); } while (0)
@@ -483,6 +514,7 @@ extern "C" int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream) {
     }
   }
   if (!aligned16(a->y)) return MTBT_EALIGN;
+  p.wgt_dev = a->wgt_dev;
   p.n_in = a->n_in; p.y = a->y; p.N = a->N; p.H = a->H; p.W = a->W; p.C = a->C; p.bug = a->add_weight_bug;
   const long total = (long)a->N * a->H * a->W * (a->C / 8);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

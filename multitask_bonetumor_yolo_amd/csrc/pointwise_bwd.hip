@@ -8,16 +8,9 @@
 #include <cmath>
 
 #include "common.h"
+#include "rowreduce.h"
 
 namespace {
-
-__device__ __forceinline__ float act_grad(float z, int act) {
-  if (act == MTBT_ACT_SILU) { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
-  if (act == MTBT_ACT_ELU) return z > 0.f ? 1.f : expf(z);
-  if (act == MTBT_ACT_GELU || act == MTBT_ACT_GELU_POLY)
-    return 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
-  return 1.f;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void act_backward_kernel(const T* __restrict__ dy, const T* __restrict__ z, T* __restrict__ dz, long n8, int act) {
@@ -48,54 +41,6 @@ __global__ __launch_bounds__(256) void channel_affine2_kernel(const T* __restric
 #pragma unroll
     for (int k = 0; k < 8; ++k) u[k] = a[ch * 8 + k] * u[k] + b[ch * 8 + k] * v[k] + d[ch * 8 + k];
     st8(out + i * 8, u);
-  }
-}
-
-constexpr int ROWS_PER_BLOCK = 256;   // pixels per workgroup in the first level
-
-// A thread owns one 16-byte chunk (8 channels) of a pixel; with fewer than 256 chunks per pixel the workgroup's threads split into
-// row groups that walk the workgroup's ROWS_PER_BLOCK pixels in parallel and are then added in row-group order through LDS
-// (deterministic).  `fetch(p, ch, v)` returns false when pixel p contributes nothing.
-template <typename F>
-__device__ __forceinline__ void rows_reduce(long p0, long p1, int chunks, float* __restrict__ dst /* [chunks*8] of this workgroup */, F fetch) {
-  __shared__ float red[256 * 8];
-  const int tid = threadIdx.x;
-  if (chunks >= 256) {
-    for (int ch = tid; ch < chunks; ch += 256) {
-      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (long p = p0; p < p1; ++p) {
-        float v[8];
-        if (fetch(p, ch, v)) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) s[k] += v[k];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) dst[ch * 8 + k] = s[k];
-    }
-    return;
-  }
-  const int rpp = 256 / chunks, rg = tid / chunks, ch = tid - rg * chunks;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (rg < rpp) {
-    for (long p = p0 + rg; p < p1; p += rpp) {
-      float v[8];
-      if (fetch(p, ch, v)) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += v[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[(rg * chunks + ch) * 8 + k] = s[k];
-  }
-  __syncthreads();
-  if (rg == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float t = 0.f;
-      for (int g = 0; g < rpp; ++g) t += red[(g * chunks + ch) * 8 + k];
-      dst[ch * 8 + k] = t;
-    }
   }
 }
 
@@ -180,17 +125,6 @@ __global__ __launch_bounds__(256) void dw_wgrad_partial(const T* __restrict__ dy
       }
     }
   }
-}
-
-// second level: one wave per output element; its lanes stride over the workgroup partials and are combined by a butterfly (fixed
-// order: deterministic).  A serial loop per element took longer than the first level once there were ~1000 partial rows.
-__global__ __launch_bounds__(256) void channel_sum_final(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;                     // whole waves leave together
-  float s = 0.f;
-  for (int b = lane; b < blocks; b += 64) s += partial[(long)b * C + c];
-  s = wave_sum(s);
-  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace

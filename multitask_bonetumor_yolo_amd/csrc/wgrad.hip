@@ -13,6 +13,7 @@
 //   reduction   fp32 partial tiles per pixel slice, summed in slice order by a second kernel (deterministic; no atomics)
 // Register double-buffering: the global loads of step t+1 are issued before the MFMAs of step t; one LDS buffer.  Its place in the plan and what comes next: DESIGN.md §7.
 #include "common.h"
+#include "rowreduce.h"
 
 namespace {
 
@@ -133,6 +134,121 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[i] = s;
 }
 
+// ---- fp32 operands (the parity mode): the same tap / slice decomposition on the VALU.  64 x 64-channel tile, 16 pixels per step staged
+// as they lie ([pixel][channel] fp32 rows), thread (ty, tx) owns a 4 x 4 block of the tile.  Not a throughput kernel: it exists so that
+// the whole backward pass can be checked against fp32 autograd. ----
+struct WgPF {
+  const float* x; const float* dy; float* partial;
+  int N, H, W, C, K, R, S, pad, stride, Ho, Wo;
+  long x_bs, dy_bs; int ldx, ldy;
+  long P, per;
+  int nsplit, ktiles, ctiles;
+};
+
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgPF p) {
+  __shared__ __attribute__((aligned(16))) float sdy[16 * 64];
+  __shared__ __attribute__((aligned(16))) float sx[16 * 64];
+  int b = blockIdx.x;
+  const int ct = b % p.ctiles; b /= p.ctiles;
+  const int kt = b % p.ktiles; b /= p.ktiles;
+  const int taps = p.R * p.S;
+  const int tap = b % taps, split = b / taps;
+  const int r = tap / p.S, s = tap - r * p.S;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int row = tid >> 4, q = tid & 15;        // staging: pixel of the step, 4-channel piece
+  const int HW = p.Ho * p.Wo;
+  const long p0 = (long)split * p.per, p1 = min(p.P, p0 + p.per);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (long pb = p0; pb < p1; pb += 16) {
+    const long pix = pb + row;
+    float4 vd = make_float4(0.f, 0.f, 0.f, 0.f), vx = vd;
+    if (pix < p1) {
+      const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
+      const int y = rem / p.Wo, xx = rem - y * p.Wo;
+      const int kch = kt * 64 + q * 4, cch = ct * 64 + q * 4;
+      if (kch < p.K) vd = *reinterpret_cast<const float4*>(p.dy + (long)n * p.dy_bs + (long)rem * p.ldy + kch);
+      const int iy = y * p.stride + r - p.pad, ix = xx * p.stride + s - p.pad;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cch < p.C)
+        vx = *reinterpret_cast<const float4*>(p.x + (long)n * p.x_bs + ((long)iy * p.W + ix) * p.ldx + cch);
+    }
+    __syncthreads();
+    *reinterpret_cast<float4*>(sdy + row * 64 + q * 4) = vd;
+    *reinterpret_cast<float4*>(sx + row * 64 + q * 4) = vx;
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp) {
+      const float4 a = *reinterpret_cast<const float4*>(sdy + pp * 64 + ty * 4);
+      const float4 c = *reinterpret_cast<const float4*>(sx + pp * 64 + tx * 4);
+      const float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], cv[j], acc[i][j]);
+    }
+  }
+  const long RSC = (long)taps * p.C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kt * 64 + ty * 4 + i, c = ct * 64 + tx * 4 + j;
+      if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)tap * p.C + c] = acc[i][j];
+    }
+}
+
+// ---- ConvNeXt stem weight gradient: dW[k][c*16 + ky*4 + kx] = sum_p d[p][k] * img[n][c][4 oy + ky][4 ox + kx]  (the 4x4 / stride-4
+// patchify conv on the caller's NCHW fp32 image, main_model.py:21-26 [timm stem_0]).  Persistent workgroups: 64 pixels per step staged in
+// LDS (48-float patches, K gradients), thread (kg, c) accumulates K/4 rows of column c in registers; per-workgroup partials. ----
+template <typename T, int KPT>
+__global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ d, int N, int H, int W, int K,
+                                                         float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* patch = reinterpret_cast<float*>(smem);   // [64][48]
+  float* dk = patch + 64 * 48;                     // [64][K]
+  const int Ho = H / 4, Wo = W / 4;
+  const long total = (long)N * Ho * Wo;
+  const int tid = threadIdx.x, c = tid % 48, kg = tid / 48;   // kg in 0..3 owns rows kg*KPT ..
+  const int kmax = min(KPT, K - kg * KPT);                      // rows of this thread inside K (<= 0: none)
+  float acc[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) acc[i] = 0.f;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    __syncthreads();
+    for (int it = tid; it < 64 * 12; it += 192) {
+      const int pix = it % 64, cky = it / 64;
+      const long gp = base + pix;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gp < total) {
+        const int n = (int)(gp / (Ho * Wo));
+        const int rem = (int)(gp - (long)n * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        v = *reinterpret_cast<const float4*>(img + (((long)n * 3 + (cky >> 2)) * H + (oy * 4 + (cky & 3))) * W + ox * 4);
+      }
+      *reinterpret_cast<float4*>(patch + pix * 48 + cky * 4) = v;
+    }
+    for (int it = tid; it < 64 * K; it += 192) {
+      const int pix = it / K, k = it - pix * K;
+      const long gp = base + pix;
+      dk[pix * K + k] = gp < total ? ld_elem<T>(d + gp * K + k) : 0.f;
+    }
+    __syncthreads();
+    for (int pix = 0; pix < 64; ++pix) {
+      const float pv = patch[pix * 48 + c];
+      const float* dr = dk + pix * K + kg * KPT;
+#pragma unroll
+      for (int i = 0; i < KPT; ++i)
+        if (i < kmax) acc[i] = fmaf(dr[i], pv, acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KPT; ++i)
+    if (i < kmax) partial[(long)blockIdx.x * K * 48 + (long)(kg * KPT + i) * 48 + c] = acc[i];
+}
+
 int pick_split(int K, int C, int taps, long P) {
   // Slices are the only parallelism beyond the (few) output tiles, but every slice writes and re-reads a full fp32 copy of dW:
   // aim at ~6 workgroups per CU while a slice keeps >= 24 steps; accept shorter slices (>= 8 steps) only to reach 2 per CU.
@@ -159,25 +275,71 @@ extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, 
                                int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
                                int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return MTBT_EINVAL;
-  if (dtype != MTBT_BF16 || C % 8 || K % 8 || x_pixel_stride % 8 || dy_pixel_stride % 8 || x_batch_stride % 8 || dy_batch_stride % 8) return MTBT_EINVAL;
+  if (dtype != MTBT_BF16 && dtype != MTBT_F32) return MTBT_EINVAL;
+  const int epc = dtype == MTBT_BF16 ? 8 : 4;   // elements per 16-byte piece
+  if (C % epc || K % epc || x_pixel_stride % epc || dy_pixel_stride % epc || x_batch_stride % epc || dy_batch_stride % epc) return MTBT_EINVAL;
   if (stride < 1 || pad < 0 || H + 2 * pad < R || W + 2 * pad < S) return MTBT_EINVAL;
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return MTBT_EALIGN;
-  if (workspace_bytes < mtbt_conv_wgrad_workspace_bytes(N, H, W, C, K, R, S)) return MTBT_EWORKSPACE;
+  const long P = (long)N * Ho * Wo;
+  const int nsplit = pick_split(K, C, R * S, P);
+  // the slices actually launched decide the workspace (a padding > (R-1)/2 makes Ho*Wo exceed H*W, beyond the documented bound)
+  if (workspace_bytes < (int64_t)nsplit * K * R * S * C * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long n = (long)K * R * S * C;
+  if (dtype == MTBT_F32) {
+    WgPF p;
+    p.x = reinterpret_cast<const float*>(x); p.dy = reinterpret_cast<const float*>(dy); p.partial = reinterpret_cast<float*>(workspace);
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.pad = pad; p.stride = stride; p.Ho = Ho; p.Wo = Wo;
+    p.x_bs = x_batch_stride; p.dy_bs = dy_batch_stride; p.ldx = x_pixel_stride; p.ldy = dy_pixel_stride;
+    p.P = P; p.nsplit = nsplit;
+    p.per = ((p.P + p.nsplit - 1) / p.nsplit + 15) / 16 * 16;
+    p.ktiles = (K + 63) / 64; p.ctiles = (C + 63) / 64;
+    const long blocks = (long)p.nsplit * R * S * p.ktiles * p.ctiles;
+    if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.partial, dw, n, p.nsplit, accumulate);
+    MTBT_LAUNCH_CHECK();
+    return MTBT_OK;
+  }
   WgP p;
   p.x = reinterpret_cast<const bf16_t*>(x); p.dy = reinterpret_cast<const bf16_t*>(dy); p.partial = reinterpret_cast<float*>(workspace);
   p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.pad = pad; p.stride = stride; p.Ho = Ho; p.Wo = Wo;
   p.x_bs = x_batch_stride; p.dy_bs = dy_batch_stride; p.ldx = x_pixel_stride; p.ldy = dy_pixel_stride;
-  p.P = (long)N * Ho * Wo;
-  p.nsplit = pick_split(K, C, R * S, p.P);
+  p.P = P;
+  p.nsplit = nsplit;
   p.per = ((p.P + p.nsplit - 1) / p.nsplit + TPX - 1) / TPX * TPX;
   p.ktiles = (K + TK - 1) / TK; p.ctiles = (C + TCH - 1) / TCH;
   const long blocks = (long)p.nsplit * R * S * p.ktiles * p.ctiles;
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
-  const long n = (long)K * R * S * C;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.partial, dw, n, p.nsplit, accumulate);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int64_t mtbt_stem_wgrad_workspace_bytes(int K) { return K <= 0 ? 0 : (int64_t)512 * K * 48 * (int64_t)sizeof(float); }
+
+// Weight gradient of the ConvNeXt stem conv (4x4, stride 4, 3 -> K channels) on the caller's NCHW fp32 image: dw [K][48] (torch's
+// [K,3,4,4] flattened) (+)= sum over the N*(H/4)*(W/4) output pixels of d[p][k] * patch(p); d dense [pixels][K] in `dtype`.  K % 4 == 0, K <= 128.
+extern "C" int mtbt_stem_wgrad(const float* x, const void* d, float* dw, int N, int H, int W, int K, int dtype, int accumulate, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  if (!x || !d || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || K <= 0 || K % 4 || K > 128) return MTBT_EINVAL;
+  if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(workspace)) return MTBT_EALIGN;
+  if (workspace_bytes < mtbt_stem_wgrad_workspace_bytes(K)) return MTBT_EWORKSPACE;
+  const long total = (long)N * (H / 4) * (W / 4);
+  long blocks = (total + 63) / 64;
+  if (blocks > 512) blocks = 512;
+  const size_t lds = (size_t)64 * (48 + K) * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+#define SW(T, KPT) hipLaunchKernelGGL((stem_wgrad_kernel<T, KPT>), dim3((unsigned)blocks), dim3(192), lds, st, x, (const T*)d, N, H, W, K, partial)
+  if (K == 96) { if (dtype == MTBT_F32) SW(float, 24); else SW(bf16_t, 24); }
+  else { if (dtype == MTBT_F32) SW(float, 32); else SW(bf16_t, 32); }
+#undef SW
+  const int n = K * 48;
+  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, (int)blocks, n, dw, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

@@ -106,7 +106,7 @@ class FlatAdamW:
             if not p.is_cuda:
                 raise RuntimeError("FlatAdamW.step: expected CUDA/HIP buckets on an MI355X (no CPU path)")
             L.check(lib.mtbt_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                        self.eps, self.weight_decay, self.steps, C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)),
+                                        self.eps, self.weight_decay, self.steps, None, C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)),
                     "mtbt_adamw_step")
 
     def cosine_lr(self, base_lr: float, epoch: int, t_max: int, eta_min_ratio: float = 0.01):
