@@ -62,12 +62,77 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"oracle fp32 forward + decode/NMS/masks, batch 1 x {n} iterations at {IMG}x{IMG}"}
 
 
+def synthetic_targets(B, S, seed, dev):
+    """per image 1-3 GT boxes (cx, cy ~ U(.2,.8), w, h ~ U(.05,.4)), masks = the filled box rectangles, image class ~ {0,1}."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    rows, masks = [], torch.zeros(B, 1, S, S)
+    for b in range(B):
+        for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+            cx, cy = (torch.rand(2, generator=g) * 0.6 + 0.2).tolist()
+            w, h = (torch.rand(2, generator=g) * 0.35 + 0.05).tolist()
+            rows.append([b, int(torch.randint(0, 2, (1,), generator=g)), cx, cy, w, h])
+            x0, x1, y0, y1 = int((cx - w / 2) * S), int((cx + w / 2) * S), int((cy - h / 2) * S), int((cy + h / 2) * S)
+            masks[b, 0, max(y0, 0):y1, max(x0, 0):x1] = 1
+    return torch.tensor(rows, dtype=torch.float32).to(dev), masks.to(dev), torch.randint(0, 2, (B,), generator=g).to(dev)
+
+
+def train_main(args, world, rank, dev):
+    """`--mode train`: BASELINE configs[2] (one GPU) / configs[3] (`--gpus N` under torch.distributed.run): forward in train mode +
+    multitask loss + backward + [bucketed RCCL all-reduce overlapped with backward] + clip + optimiser, batch 32 per GPU, 640x640.
+    A SIDE measurement: the headline line of this file stays configs[1]."""
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, init_synthetic_
+    from multitask_bonetumor_yolo_amd.trainstep import TrainStep
+    from multitask_bonetumor_yolo_amd.dist_utils import timed_steps
+    torch.manual_seed(0)
+    model = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    B, S = args.batch, args.img
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(rank)).to(dev)
+    boxes, masks, cls = synthetic_targets(B, S, rank, dev)
+    ts = TrainStep(model, (B, 3, S, S), optimizer=args.optimizer, lr=1e-4)
+    out = {}
+
+    def step():
+        out["loss"] = ts.step(x, boxes, masks, cls)
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(step, args.steps, lambda: torch.cuda.synchronize(dev))
+    if rank == 0:
+        loss = out["loss"].float().cpu().tolist()
+        tp = ts.tp
+        fwd_ms, bwd_ms = tp.fwd.run_timed(), ts.bwd.run_timed()
+        if args.kernel_table:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "train_layer_times.json"), "w") as f:
+                json.dump({"fwd": [{"name": l.name, "us": t * 1e3, "flops": l.flops} for l, t in zip(tp.fwd.launches, fwd_ms)],
+                           "bwd": [{"name": l.name, "us": t * 1e3, "flops": l.flops} for l, t in zip(ts.bwd.launches, bwd_ms)]}, f)
+            for tag, plan, ms in (("fwd", tp.fwd, fwd_ms), ("bwd", ts.bwd, bwd_ms)):
+                for l, t in sorted(zip(plan.launches, ms), key=lambda p: -p[1])[:25]:
+                    print(f"{tag} {t*1e3:9.1f} us  {l.flops/(t*1e-3)/1e12 if t > 0 else 0:7.1f} TF/s  {l.name}", file=sys.stderr)
+        flop_per_img = 545e9 * (S / 640.0) ** 2        # SURVEY 8(d): ~3x the 181.8 GFLOP forward
+        ms_step = elapsed / args.steps * 1e3
+        line = {"metric": "images/sec, training step (fwd + multitask loss + bwd + clip + optimizer) at 640x640", "value": round(world * B * args.steps / elapsed, 2),
+                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"configs[{2 if world == 1 else 3}]: batch-{B}/GPU {S}x{S} training step, {args.optimizer}, clip 10; random-init weights; "
+                                       f"{'single GPU' if world == 1 else 'DDP: bucketed RCCL all-reduce overlapped with backward'}",
+                           "batch_per_gpu": B, "img": S, "parallelism": f"dp{world}", "fwd_launches": len(tp.fwd.launches), "bwd_launches": len(ts.bwd.launches),
+                           "fwd_kernel_ms": round(sum(fwd_ms), 3), "bwd_kernel_ms": round(sum(bwd_ms), 3), "loss_total": loss[0], "n_pos": loss[6],
+                           "grad_norm": float(ts.gnorm.item()), "kept_activation_GiB": round(tp.fwd.pool.bytes / 2**30, 2)},
+                "roofline": {"bound": "mfma", "kernel": "whole training step (all kernels)", "achieved": round(B * flop_per_img / (ms_step * 1e-3) / 1e12, 2),
+                             "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                             "frac": round(B * flop_per_img / (ms_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None}}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="infer = the headline (configs[1]); train = configs[2]/[3] side line")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adamw"], help="train mode: BASELINE configs[2] names SGD; the reference trainer uses AdamW")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (infer) / 32 (train)")
     ap.add_argument("--img", type=int, default=IMG, help="image side (default 640 = the benchmark configuration; 1280 = BASELINE configs[4]'s shape)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,6 +141,8 @@ def main():
     ap.add_argument("--ab-graph", default="", help="dev: comma list of VAR=val; each is re-lowered, re-captured and its graph replay timed")
     ap.add_argument("--ab", default="", help="dev: comma list of MTBT_CONV_POLICY values to A/B inside this process")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = BATCH_PER_GPU if args.mode == "infer" else 32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,6 +158,12 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.mode == "train":
+        train_main(args, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, GraphedInference, init_synthetic_, postprocess as pp
 

@@ -421,13 +421,14 @@ typedef struct mtbt_prep_desc {
   int32_t flip[4];
   int32_t scale0_dim, scale1_dim;
   int32_t dst_dtype;
-  int32_t reserved;
+  int32_t src_dim3; /* > 0: the source has only src_dim3 entries along dim 3; dst[..][d >= src_dim3] = 0 (channel padding) */
 } mtbt_prep_desc;
 int mtbt_weight_prep_blocks(int64_t elements);
 int mtbt_weight_prep(const mtbt_prep_desc* table_dev, const int32_t* block_start_dev, int n_desc, int total_blocks, void* stream);
 
-/* BiFPN fusion weights on the device (main_model.py:194-196): out[i][j] = ELU(w[i][j]) / (sum_i ELU(w[i][j]) + eps), w [n][2]
- * (n = 2: w1, n = 3: w2), and the backward of that normalisation (dw (+)= J^T dout). */
+/* BiFPN fusion weights on the device (main_model.py:194-196): out[j][i] = ELU(w[i][j]) / (sum_i ELU(w[i][j]) + eps), w [n][2]
+ * (n = 2: w1, n = 3: w2); out / dout are TRANSPOSED [2][n] so that the n weights of fusion node j are contiguous (wgt_dev of
+ * mtbt_bifpn_fuse).  The backward of that normalisation: dw [n][2] (+)= J^T dout. */
 int mtbt_bifpn_norm_weights(const float* w, int n, float eps, float* out, void* stream);
 int mtbt_bifpn_norm_weights_backward(const float* w, int n, float eps, const float* dout, float* dw, int accumulate, void* stream);
 

@@ -72,7 +72,7 @@ class LossArgs(C.Structure):
 class PrepDesc(C.Structure):  # mtbt_prep_desc
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale0", C.c_void_p), ("scale1", C.c_void_p),
                 ("sstride", C.c_int64 * 4), ("dim", C.c_int32 * 4), ("flip", C.c_int32 * 4),
-                ("scale0_dim", C.c_int32), ("scale1_dim", C.c_int32), ("dst_dtype", C.c_int32), ("reserved", C.c_int32)]
+                ("scale0_dim", C.c_int32), ("scale1_dim", C.c_int32), ("dst_dtype", C.c_int32), ("src_dim3", C.c_int32)]
 
 
 class RawImage(C.Structure):  # mtbt_raw_image

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const mtbt_prep_desc* 
     long off = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) off += (long)(d.flip[q] ? d.dim[q] - 1 - idx[q] : idx[q]) * d.sstride[q];
-    float v = d.src[off];
+    float v = (d.src_dim3 > 0 && idx[3] >= d.src_dim3) ? 0.f : d.src[off];   // zero padding of the last dimension
     if (d.scale0) v *= d.scale0[idx[d.scale0_dim]];
     if (d.scale1) v *= d.scale1[idx[d.scale1_dim]];
     if (d.dst_dtype == MTBT_F32) reinterpret_cast<float*>(d.dst)[e] = v;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const mtbt_prep_desc* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// BiFPN fusion weights (main_model.py:194-196): e = ELU(w), out[i][j] = e[i][j] / (sum_i e[i][j] + eps), w [n][2].
+// BiFPN fusion weights (main_model.py:194-196): e = ELU(w), out[j][i] = e[i][j] / (sum_i e[i][j] + eps), w [n][2]; out (and dout of the
+// backward) is TRANSPOSED, [2][n]: the n weights of fusion node j are contiguous, as mtbt_bifpn_fuse's wgt_dev wants them.
 // ------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
 
@@ -182,7 +183,7 @@ __global__ void bifpn_norm_kernel(const float* __restrict__ w, int n, float eps,
   if (j >= 2) return;
   float s = 0.f;
   for (int i = 0; i < n; ++i) s += elu1(w[i * 2 + j]);
-  for (int i = 0; i < n; ++i) out[i * 2 + j] = elu1(w[i * 2 + j]) / (s + eps);
+  for (int i = 0; i < n; ++i) out[j * n + i] = elu1(w[i * 2 + j]) / (s + eps);   // transposed: a node's n weights are contiguous
 }
 
 __global__ void bifpn_norm_bwd_kernel(const float* __restrict__ w, int n, float eps, const float* __restrict__ dout, float* __restrict__ dw,
@@ -190,11 +191,11 @@ __global__ void bifpn_norm_bwd_kernel(const float* __restrict__ w, int n, float 
   const int j = threadIdx.x;
   if (j >= 2) return;
   float s = 0.f, dot = 0.f;
-  for (int i = 0; i < n; ++i) { const float e = elu1(w[i * 2 + j]); s += e; dot += dout[i * 2 + j] * e; }
+  for (int i = 0; i < n; ++i) { const float e = elu1(w[i * 2 + j]); s += e; dot += dout[j * n + i] * e; }
   const float inv = 1.f / (s + eps);
   for (int i = 0; i < n; ++i) {
     const float p = w[i * 2 + j];
-    const float de = dout[i * 2 + j] * inv - dot * inv * inv;
+    const float de = dout[j * n + i] * inv - dot * inv * inv;
     const float g = de * (p > 0.f ? 1.f : expf(p));
     dw[i * 2 + j] = accumulate ? dw[i * 2 + j] + g : g;
   }

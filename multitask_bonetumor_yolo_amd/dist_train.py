@@ -26,18 +26,21 @@ class FlatBuckets:
     `views[name]` is a tensor of the registered shape aliasing its slice of a bucket; every slice starts on a 16-byte
     boundary (the kernels' vector accesses)."""
 
-    def __init__(self, named_shapes: Sequence[Tuple[str, Sequence[int]]], device, bucket_bytes: int = BUCKET_BYTES):
+    def __init__(self, named_shapes: Sequence[Tuple[str, Sequence[int]]], device, bucket_bytes: int = BUCKET_BYTES, close_after: Sequence[str] = ()):
+        """`close_after`: names after which (in fill order = reverse registration order) the current bucket is closed whatever its
+        size -- a group of tensors that must not share a bucket with the rest (parameters that never receive a gradient)."""
         self.views: Dict[str, torch.Tensor] = {}
         self.buckets: List[torch.Tensor] = []
         self.layout: List[List[Tuple[str, int, int]]] = []          # per bucket: (name, offset, numel)
         cur, off = [], 0
+        close_after = set(close_after)
         for name, shape in reversed(list(named_shapes)):
             n = 1
             for d in shape:
                 n *= int(d)
             cur.append((name, off, n, tuple(shape)))
             off += (n + 3) // 4 * 4
-            if off * 4 >= bucket_bytes:
+            if off * 4 >= bucket_bytes or name in close_after:
                 self._close(cur, off, device)
                 cur, off = [], 0
         if cur:
@@ -62,10 +65,12 @@ class FlatBuckets:
             return []
         world = dist.get_world_size()
         works = []
+        if stream is not None:
+            # the compute stream as seen OUTSIDE the side-stream context (inside it current_stream() is the side stream itself and the
+            # wait would be a no-op: the collective could then start before the gradients are written)
+            stream.wait_stream(torch.cuda.current_stream(self.buckets[0].device if self.buckets[0].is_cuda else None))
         ctx = torch.cuda.stream(stream) if stream is not None else _null()
         with ctx:
-            if stream is not None:
-                stream.wait_stream(torch.cuda.current_stream())
             for b in self.buckets:
                 b.div_(world)                                      # pre-scale: SUM of the scaled buckets = mean, no overflow headroom lost
                 works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True))

@@ -43,7 +43,7 @@ def group_gt_boxes(gt_boxes: torch.Tensor, n_images: int, img_size: float):
 def multitask_loss(det_maps: Sequence[torch.Tensor], protos: torch.Tensor, img_logits: torch.Tensor, gt_boxes: torch.Tensor,
                    gt_masks: torch.Tensor, gt_cls: torch.Tensor, proj_weight: torch.Tensor, proj_bias: torch.Tensor, *, img_size: int,
                    nc_det: int, reg_max: int = 16, iou_match_thresh: float = 0.5, label_smoothing: float = 0.0, training: bool = True,
-                   weights=(1.0, 2.0, 1.5, 0.5, 1.0), with_grads: bool = False):
+                   weights=(1.0, 2.0, 1.5, 0.5, 1.0), with_grads: bool = False, grad_out=None):
     """det_maps: the raw Detect maps of `forward(x, "train")` (3 x [B, 4*reg_max+nc, h, w]); protos [B, nm, hp, wp];
     gt_masks [B,1,S,S] float; gt_cls [B] int64; proj_*: the trainer's `seg_proto_projector` (`:186`).
     Returns the reference's tuple as 0-d fp32 tensors: (total, seg, box, dfl, cls_det, img_cls[, n_pos, mean matched IoU]).
@@ -86,11 +86,13 @@ def multitask_loss(det_maps: Sequence[torch.Tensor], protos: torch.Tensor, img_l
         return res
     # gradient of the total w.r.t. the head outputs (csrc/loss.hip: det_loss_grad_kernel, seg_img_grad_kernel)
     no = 4 * reg_max + nc_det
-    d_maps = [torch.empty(m.shape[0], m.shape[2], m.shape[3], no, dtype=torch.float32, device=dev) for m in det_maps]
+    # grad_out = {"det_maps": [NHWC fp32 buffers], "img_logits": [B, n] fp32}: write straight into a training plan's input buffers
+    d_maps = (list(grad_out["det_maps"]) if grad_out is not None else
+              [torch.empty(m.shape[0], m.shape[2], m.shape[3], no, dtype=torch.float32, device=dev) for m in det_maps])
     ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in d_maps], *([None] * (3 - len(d_maps))))
     lds = (C.c_int32 * 3)(*([no] * len(d_maps)), *([0] * (3 - len(d_maps))))
     d_seg = torch.empty_like(seg_logits)
-    d_img = torch.empty_like(il)
+    d_img = grad_out["img_logits"] if grad_out is not None else torch.empty_like(il)
     L.check(lib.mtbt_multitask_loss_grad(C.byref(a), ptrs, lds, d_seg.data_ptr(), d_img.data_ptr(), _stream(dev)), "mtbt_multitask_loss_grad")
     del keep
     grads = {"det_maps": [t.permute(0, 3, 1, 2) for t in d_maps],      # [B, no, h, w] views of channels-last memory

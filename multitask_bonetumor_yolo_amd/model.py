@@ -565,6 +565,14 @@ class _Base(nn.Module):
     def _heads(self):
         raise NotImplementedError
 
+    def _wants_training_plan(self) -> bool:
+        """forward(x, "train") goes through the training lowering when autograd is recording on a trainable model, or when a
+        backbone / neck BatchNorm is in train mode (batch statistics into C2f slices: only train.py lowers those)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return True
+        heads = {id(m) for h in (getattr(self, "detect", None), self.segment) if h is not None for m in h.modules()}
+        return any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d) and id(m) not in heads)
+
     def compile(self, x: torch.Tensor) -> "_Compiled":
         """Lower the graph for this input's shape/dtype policy (cached until weights or BN modes change)."""
         if not x.is_cuda:
@@ -708,6 +716,12 @@ class ConvNeXtBiFPNYOLO(_Base):
             if mode == "train":      # main_model.py:357-365
                 self.detect.train()
                 self.segment.train()
+                if self._wants_training_plan():
+                    # model.train() and / or autograd recording: the training lowering (train.py) keeps what backward needs and
+                    # returns tensors whose grad_fn runs the backward plan -- `total_loss.backward()` of running_main_v3.py:393-445
+                    from .train import train_forward
+                    det, seg, mc, protos, logits = train_forward(self, x)
+                    return det, (seg, mc, protos), logits
                 c = self._run(x)
                 det = [m.nchw().clone() for m in c.det_maps]
                 seg = [m.nchw().clone() for m in c.seg_maps]
@@ -756,6 +770,10 @@ class ConvNeXtBiFPNYOLOv2(_Base):
         try:
             if mode == "train":      # main_modelv2.py:353-360
                 self.segment.train()
+                if self._wants_training_plan():
+                    from .train import train_forward
+                    _, seg, mc, protos, logits = train_forward(self, x)
+                    return (seg, mc, protos), logits
                 c = self._run(x)
                 seg = [m.nchw().clone() for m in c.seg_maps]
                 return (seg, c.mc.permute(0, 2, 1).clone(), c.protos.nchw().clone()), c.logits.clone()

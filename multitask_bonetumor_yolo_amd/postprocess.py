@@ -178,8 +178,8 @@ def proto_projector_logits(protos: torch.Tensor, weight: torch.Tensor, bias: tor
     """Trainer's seg_proto_projector path (running_main_v3.py:186, :251-255): Conv2d(nm,1,1)(protos) then bilinear
     to img_size.  Returns logits [B,1,S,S] fp32."""
     w = weight.detach().reshape(-1).float().contiguous()
-    logits, _ = _mask_call(protos, w, 0, 0, 1, None, None, float(bias.detach().reshape(-1)[0]), 1, (img_size, img_size), True, False)
-    return logits
+    logits, _ = _mask_call(protos, w, 0, 0, 1, None, None, 0.0, 1, (img_size, img_size), True, False)
+    return logits.add_(bias.detach().reshape(1, 1, 1, 1).to(logits.dtype))      # device-side add: no host synchronisation (bilinear weights sum to 1)
 
 
 def detect_and_segment(det_maps: List[torch.Tensor], mc: torch.Tensor, protos: torch.Tensor, img_size: int,

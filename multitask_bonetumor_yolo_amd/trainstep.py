@@ -1,0 +1,196 @@
+"""The whole training step of BASELINE configs[2]-[3] as device work with no autograd graph and no host synchronisation:
+
+    forward (train.TrainPlan) -> `_multitask_loss` + its gradient (csrc/loss.hip) -> proto-projector backward -> backward plan
+    -> [data-parallel: one RCCL all-reduce per gradient bucket, issued on a side stream the moment the bucket's last producer has
+       been launched, so that it runs UNDER the rest of the backward pass] -> global-norm clip -> fused AdamW / SGD over flat buckets
+
+It is what `/root/reference/src/running_main_v3.py:393-445` (`training_step`) + Lightning's `backward` / `clip_gradients(10)` /
+`optimizer.step()` (`:732-743`, `:824-828`) do per batch, with the reference's hyper-parameters as defaults.  The drop-in route --
+`model(x, "train")` returning autograd tensors for the reference's own Lightning loop -- is `train.train_forward`; this class is the
+same two launch plans driven natively.
+
+Parameters are RE-HOMED once into flat fp32 buckets (`dist_train.FlatBuckets`) laid out exactly like the gradient buckets -- each
+`nn.Parameter` keeps its name, shape and values but becomes a (channels-last) view of a bucket -- so the optimiser is one fused
+launch per bucket and DDP's "unused parameter" problem (Segment.cv2 / cv3 / cv4 never reach the loss) is solved by
+layout: those parameters live in their own leading bucket that is neither reduced nor stepped, which is also what torch's
+optimisers do with `grad is None`.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import code_of
+from .loss import multitask_loss
+from .train import TrainPlan, make_arena
+
+UNUSED_BY_THE_LOSS = ("segment.cv2.", "segment.cv3.", "segment.cv4.")   # running_main_v3.py:239-257 reads only seg_head_outputs[2]
+
+
+def _s(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class TrainStep:
+    def __init__(self, model, batch_shape: Sequence[int], *, optimizer: str = "adamw", lr: float = 1e-4, weight_decay: float = 5e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9, nesterov: bool = False, clip_norm: Optional[float] = 10.0,
+                 iou_match_thresh: float = 0.5, label_smoothing: float = 0.1, loss_weights=(1.0, 2.0, 1.5, 0.5, 1.0),
+                 projector: Optional[nn.Conv2d] = None, process_group=None, overlap: bool = True):
+        """batch_shape [B,3,S,S] per rank.  `projector` = the trainer's `seg_proto_projector` (Conv2d(proto_ch, 1, 1),
+        running_main_v3.py:186); created (seeded default init) when not given.  A live `torch.distributed` process group with more than
+        one rank turns on the gradient exchange; parameters are broadcast from rank 0 first (what DDP does at construction)."""
+        if not hasattr(model, "detect"):
+            raise NotImplementedError("TrainStep drives the canonical model (running_main_v3.py needs .detect, SURVEY F4)")
+        self.m = model
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("TrainStep: the model must live on an MI355X (no CPU path)")
+        self.dev, self.lib = dev, L.load()
+        self.B, _, self.S, _ = batch_shape
+        model.train()
+        self.projector = projector if projector is not None else nn.Conv2d(model.proto_ch, 1, 1)
+        self.projector.to(dev)
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.group = process_group
+        # ---- re-home the parameters into flat buckets with the gradient arena's layout ----
+        self.params, gview, self.n_skip = make_arena(model, dev, UNUSED_BY_THE_LOSS)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if not p.requires_grad:
+                    continue
+                v = self.params.views[name]
+                v = gview[name](v) if gview[name] is not None else v
+                v.copy_(p.data)
+                p.data = v
+            if self.world > 1:
+                for b in self.params.buckets:
+                    dist.broadcast(b, src=0, group=process_group)
+                for buf in model.buffers():
+                    dist.broadcast(buf, src=0, group=process_group)
+                for p in self.projector.parameters():
+                    dist.broadcast(p.data, src=0, group=process_group)
+        model.__dict__.pop("_train_plans", None)
+        self.tp = TrainPlan(model, tuple(batch_shape), dev, code_of(model.compute_dtype), tail_prefixes=UNUSED_BY_THE_LOSS)
+        assert [b.numel() for b in self.tp.arena.buckets] == [b.numel() for b in self.params.buckets]
+        self.grads = self.tp.arena
+        self.active = ("det", "logits", "protos")
+        self.bwd = self.tp.backward_plan(self.active)
+        # the projector's three tensors: tiny flat buffers of their own
+        nm = model.proto_ch
+        self.pj = torch.zeros(nm + 4, device=dev)                      # weight [nm], bias [1]
+        self.pj_grad, self.pj_m, self.pj_v = torch.zeros_like(self.pj), torch.zeros_like(self.pj), torch.zeros_like(self.pj)
+        with torch.no_grad():
+            self.pj[:nm].copy_(self.projector.weight.detach().view(-1))
+            self.pj[nm:nm + 1].copy_(self.projector.bias.detach().view(-1))
+            self.projector.weight.data = self.pj[:nm].view(1, nm, 1, 1)
+            self.projector.bias.data = self.pj[nm:nm + 1]
+        nb = self.lib.mtbt_projector_backward_workspace_bytes(self.B, self.S // 4, self.S // 4, nm)
+        self.pj_ws = torch.empty(nb // 4, device=dev)
+        # ---- optimiser state over the stepped buckets ----
+        self.opt, self.lr, self.wd, self.betas, self.eps = optimizer, lr, weight_decay, betas, eps
+        self.momentum, self.nesterov, self.clip_norm = momentum, nesterov, clip_norm
+        if optimizer not in ("adamw", "sgd"):
+            raise ValueError("optimizer: 'adamw' (the reference trainer, running_main_v3.py:732) or 'sgd' (BASELINE configs[2])")
+        self.m1 = [torch.zeros_like(b) for b in self.params.buckets]
+        self.m2 = [torch.zeros_like(b) for b in self.params.buckets] if optimizer == "adamw" else None
+        self.steps = 0
+        self.sq, self.coef, self.gnorm = torch.zeros(1, device=dev), torch.ones(1, device=dev), torch.zeros(1, device=dev)
+        self.sq_ws = torch.empty(self.lib.mtbt_sumsq_workspace_bytes() // 4, device=dev)
+        self.loss_kw = dict(img_size=self.S, nc_det=model.nc_det, reg_max=model.detect.reg_max, iou_match_thresh=iou_match_thresh,
+                            label_smoothing=label_smoothing, training=True, weights=loss_weights)
+        # ---- gradient exchange: bucket b is complete after backward launch ready[b] ----
+        self.comm = torch.cuda.Stream(device=dev) if (self.world > 1 and overlap) else None
+        self.ready = self._bucket_ready_indices()
+
+    def _bucket_ready_indices(self):
+        """Per gradient bucket the index of the LAST backward launch that writes into it (known statically: no hooks)."""
+        last = {}
+        for i, l in enumerate(self.bwd.launches):
+            for k in l.keep:
+                if isinstance(k, torch.Tensor):
+                    last[id(k)] = i
+        out = []
+        for lay in self.grads.layout:
+            idx = [last.get(id(self.grads.views[n]), -1) for n, _, _ in lay]
+            out.append(max(idx) if idx else -1)
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def step(self, x: torch.Tensor, gt_boxes: torch.Tensor, gt_masks: torch.Tensor, gt_cls: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on this rank's shard.  Returns the loss tuple of `_multitask_loss` as an 8-element device tensor view
+        (total, seg, box, dfl, cls_det, img_cls, #positives, mean matched IoU) -- no host synchronisation."""
+        tp, lib, dev = self.tp, self.lib, self.dev
+        tp.run_forward(x)
+        nm = self.m.proto_ch
+        res, g = multitask_loss([m.nchw() for m in tp.det_maps], tp.protos.nchw(), tp.logits, gt_boxes, gt_masks, gt_cls, self.projector.weight,
+                                self.projector.bias, with_grads=True,
+                                grad_out={"det_maps": [d.buf for d in tp.d_in["det"]], "img_logits": tp.d_in["logits"]}, **self.loss_kw)
+        dseg = g["seg_logits"]
+        L.check(lib.mtbt_projector_backward(dseg.data_ptr(), tp.protos.ptr, self.pj.data_ptr(), tp.d_in["protos"].data_ptr(), tp.code, 0,
+                                            self.pj_grad.data_ptr(), self.pj_grad.data_ptr() + 4 * nm, 0, self.B, self.S // 4, self.S // 4, nm, self.S, self.S,
+                                            self.pj_ws.data_ptr(), self.pj_ws.numel() * 4, _s(dev)), "mtbt_projector_backward")
+        self._backward_and_exchange()
+        self._clip_and_update()
+        self.m.__dict__["_bn_epoch"] = self.m.__dict__.get("_bn_epoch", 0) + 1     # inference plans folded the old weights / statistics
+        return torch.stack(res)
+
+    def _backward_and_exchange(self):
+        main = torch.cuda.current_stream(self.dev)
+        if self.world == 1:
+            self.bwd.run(stream=main.cuda_stream)
+            return
+        live = list(range(self.n_skip, len(self.grads.buckets)))
+        if self.comm is None:
+            self.bwd.run(stream=main.cuda_stream)
+            for b in live:
+                self.grads.buckets[b].div_(self.world)
+                dist.all_reduce(self.grads.buckets[b], op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce_projector()
+            return
+        marks = {str(b): [self.ready[b]] for b in live if self.ready[b] >= 0}
+        events = self.bwd.run(stream=main.cuda_stream, marks=marks)
+        # buckets complete in bucket order (reverse registration = backward order); each collective waits only for ITS last producer
+        with torch.cuda.stream(self.comm):
+            for b in sorted(live, key=lambda k: self.ready[k]):
+                for ev in events.get(str(b), []):
+                    self.comm.wait_event(ev)
+                self.grads.buckets[b].div_(self.world)                 # pre-scaled SUM = mean
+                dist.all_reduce(self.grads.buckets[b], op=dist.ReduceOp.SUM, group=self.group)
+        main.wait_stream(self.comm)
+        self._reduce_projector()
+
+    def _reduce_projector(self):
+        self.pj_grad.div_(self.world)
+        dist.all_reduce(self.pj_grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _clip_and_update(self):
+        lib, s = self.lib, _s(self.dev)
+        self.steps += 1
+        live = list(range(self.n_skip, len(self.grads.buckets)))
+        scale = None
+        if self.clip_norm is not None:
+            first = True
+            for t in [self.grads.buckets[b] for b in live] + [self.pj_grad]:
+                L.check(lib.mtbt_sumsq(t.data_ptr(), t.numel(), self.sq.data_ptr(), 0 if first else 1, self.sq_ws.data_ptr(), self.sq_ws.numel() * 4, s), "mtbt_sumsq")
+                first = False
+            L.check(lib.mtbt_clip_coef(self.sq.data_ptr(), float(self.clip_norm), self.coef.data_ptr(), self.gnorm.data_ptr(), s), "mtbt_clip_coef")
+            scale = self.coef.data_ptr()
+        targets = [(self.params.buckets[b], self.grads.buckets[b], self.m1[b], self.m2[b] if self.m2 else None) for b in live]
+        targets.append((self.pj, self.pj_grad, self.pj_m, self.pj_v if self.opt == "adamw" else None))
+        for p, g, m1, m2 in targets:
+            if self.opt == "adamw":
+                L.check(lib.mtbt_adamw_step(p.data_ptr(), g.data_ptr(), m1.data_ptr(), m2.data_ptr(), p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                            self.wd, self.steps, scale, s), "mtbt_adamw_step")
+            else:
+                L.check(lib.mtbt_sgd_step(p.data_ptr(), g.data_ptr(), m1.data_ptr(), p.numel(), self.lr, self.momentum, 0.0, self.wd, int(self.nesterov),
+                                          self.steps, scale, s), "mtbt_sgd_step")
+
+    def cosine_lr(self, base_lr: float, epoch: int, t_max: int, eta_min_ratio: float = 0.01) -> float:
+        """CosineAnnealingLR(T_max, eta_min = 0.01 * lr) in closed form (running_main_v3.py:742), applied per epoch."""
+        import math
+        eta_min = base_lr * eta_min_ratio
+        self.lr = eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
+        return self.lr

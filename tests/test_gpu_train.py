@@ -1,0 +1,220 @@
+"""The assembled training step behind the Module (BASELINE configs[2]): `forward(x, "train")` under `model.train()` returns tensors
+with autograd history; `.backward()` runs the HIP backward plan.  Every parameter gradient is compared with torch autograd through
+the oracle model on the same state_dict and inputs (fp32 mode: <= 1e-3 relative to the gradient's largest entry).
+
+Reference call stack this mirrors: `/root/reference/src/running_main_v3.py:393-445` (training_step -> _multitask_loss -> Lightning's
+backward) over `/root/reference/src/main_model.py:342-365`."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+if torch.cuda.is_available():
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv2
+    from oracle import loss as oloss
+    from oracle.model import ConvNeXtBiFPNYOLO as OModel, ConvNeXtBiFPNYOLOv2 as OModelV2, randomize_
+
+
+def build(variant="main", seed=0, train=True):
+    torch.manual_seed(seed)
+    ocls, hcls = (OModel, ConvNeXtBiFPNYOLO) if variant == "main" else (OModelV2, ConvNeXtBiFPNYOLOv2)
+    ora = randomize_(ocls(2, 2, pretrained_backbone=False), seed)
+    hip = hcls(2, 2, pretrained_backbone=False)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    ora.train(train)
+    hip.train(train)
+    return ora, hip
+
+
+def flat_outputs(out):
+    """(det list | absent, (seg list, mc, protos), logits) -> flat list of tensors in a fixed order"""
+    if len(out) == 3:
+        det, (seg, mc, protos), logits = out
+        return list(det) + list(seg) + [mc, protos, logits]
+    (seg, mc, protos), logits = out
+    return list(seg) + [mc, protos, logits]
+
+
+def compare_grads(ora, hip, rtol, what, allow_none=()):
+    bad = []
+    ref_scale = max(p.grad.abs().max().item() for p in ora.parameters() if p.grad is not None)
+    hp = dict(hip.named_parameters())
+    for name, p in ora.named_parameters():
+        g = hp[name].grad
+        if p.grad is None:
+            assert g is None, f"{name}: oracle has no gradient, HIP has one"
+            continue
+        if g is None:
+            if any(name.startswith(a) for a in allow_none):
+                continue
+            bad.append(f"{name}: missing")
+            continue
+        g = g.float().cpu()
+        err = (g - p.grad).abs().max().item()
+        scale = p.grad.abs().max().item()
+        # absolute floor: conv biases in front of a batch-statistic BatchNorm have an exactly-zero gradient (autograd returns rounding
+        # noise there), and a few scalars are tiny next to the rest of the network
+        if err > rtol * scale + 1e-6 * ref_scale:
+            bad.append(f"{name}: err {err:.3e} scale {scale:.3e} ({tuple(p.shape)})")
+    assert not bad, f"{what}: {len(bad)} parameter gradients differ:\n" + "\n".join(bad[:60])
+
+
+@pytest.mark.parametrize("variant", ["main", "v2"])
+def test_every_parameter_gradient_matches_autograd_fp32(variant):
+    """model.train(): batch-statistic BatchNorm everywhere (C2f slices included).  The loss is a fixed random linear functional of ALL
+    outputs, so that every parameter -- Segment's cv2 / cv3 / cv4, which the reference's loss never reaches, included -- gets a gradient."""
+    ora, hip = build(variant)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 128, 128, generator=g)
+    ro = flat_outputs(ora(x, "train"))
+    ho = flat_outputs(hip(x.to(DEV), "train"))
+    worst = 0.0
+    for r, h in zip(ro, ho):
+        assert tuple(r.shape) == tuple(h.shape)
+        worst = max(worst, (h.detach().float().cpu() - r.detach()).abs().max().item())
+    assert worst < 1e-3, f"train-mode forward differs from the oracle by {worst}"
+    probes = [torch.randn(r.shape, generator=g) / r[0].numel() ** 0.5 for r in ro]
+    sum((r * w).sum() for r, w in zip(ro, probes)).backward()
+    sum((h * w.to(DEV)).sum() for h, w in zip(ho, probes)).backward()
+    torch.cuda.synchronize()
+    compare_grads(ora, hip, 1e-3, f"{variant} fp32")
+    # running statistics / num_batches_tracked moved exactly like the oracle's
+    hb = dict(hip.named_buffers())
+    for name, b in ora.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(hb[name]) == int(b), name
+        elif name.endswith("running_mean") or name.endswith("running_var"):
+            assert (hb[name].cpu() - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-3), name
+
+
+def test_training_step_with_the_reference_loss_fp32():
+    """forward(train) -> the trainer's `_multitask_loss` (oracle restatement, plain torch ops on the returned tensors) -> backward:
+    what `running_main_v3.py:393-445` does.  Only the Detect maps, the prototypes and the image logits reach the loss, so Segment's
+    cv2 / cv3 / cv4 get NO gradient -- in the oracle and here alike."""
+    ora, hip = build("main", seed=1)
+    g = torch.Generator().manual_seed(7)
+    S = 128
+    x = torch.rand(2, 3, S, S, generator=g)
+    gt_boxes = torch.tensor([[0, 1, 0.5, 0.5, 0.4, 0.3], [1, 0, 0.4, 0.6, 0.5, 0.5]])
+    gt_masks = torch.zeros(2, 1, S, S)
+    gt_masks[0, 0, 45:83, 38:90] = 1
+    gt_masks[1, 0, 45:109, 19:83] = 1
+    gt_cls = torch.tensor([1, 0])
+    proj = torch.nn.Conv2d(32, 1, 1)
+    kw = dict(img_size=S, nc_det=2, iou_match_thresh=0.05, label_smoothing=0.1, training=True)     # low threshold: random heads still match
+
+    det_r, (_, _, protos_r), logits_r = ora(x, "train")
+    lr = oloss.multitask_loss(det_r, protos_r, logits_r, gt_boxes, gt_masks, gt_cls, proj.weight, proj.bias, **kw)
+    # the same torch loss on CPU copies that keep the autograd link to the HIP outputs
+    det, (seg, mc, protos), logits = hip(x.to(DEV), "train")
+    lh = oloss.multitask_loss([d.cpu() for d in det], protos.cpu(), logits.cpu(), gt_boxes, gt_masks, gt_cls, proj.weight, proj.bias, **kw)
+    assert lr[6].item() > 0, "the synthetic batch must produce positive matches"
+    assert abs(lh[0].item() - lr[0].item()) <= 1e-3 * abs(lr[0].item())
+    lr[0].backward()
+    lh[0].backward()
+    torch.cuda.synchronize()
+    compare_grads(ora, hip, 1e-3, "reference loss fp32")
+    hp = dict(hip.named_parameters())
+    for name in ("segment.cv2.0.0.conv.weight", "segment.cv3.1.2.weight", "segment.cv4.2.2.bias"):
+        assert hp[name].grad is None
+
+
+def test_eval_mode_backbone_backward_fp32():
+    """model.eval() with autograd on (frozen BatchNorm statistics in backbone / neck; the heads are flipped to train mode by forward,
+    main_model.py:358-359): running-statistic BatchNorm backward, conv biases get real gradients."""
+    ora, hip = build("main", seed=2, train=False)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 96, 96, generator=g)
+    ro, ho = flat_outputs(ora(x, "train")), flat_outputs(hip(x.to(DEV), "train"))
+    probes = [torch.randn(r.shape, generator=g) / r[0].numel() ** 0.5 for r in ro]
+    sum((r * w).sum() for r, w in zip(ro, probes)).backward()
+    sum((h * w.to(DEV)).sum() for h, w in zip(ho, probes)).backward()
+    torch.cuda.synchronize()
+    compare_grads(ora, hip, 1e-3, "eval-mode backbone fp32")
+
+
+def test_bf16_training_step_gradients_are_close_and_finite():
+    """bf16 storage (the throughput mode): gradients stay finite and point the same way as fp32 autograd's."""
+    ora, hip = build("main", seed=3)
+    hip.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(4, 3, 128, 128, generator=g)
+    ro, ho = flat_outputs(ora(x, "train")), flat_outputs(hip(x.to(DEV), "train"))
+    probes = [torch.randn(r.shape, generator=g) / r[0].numel() ** 0.5 for r in ro]
+    sum((r * w).sum() for r, w in zip(ro, probes)).backward()
+    sum((h * w.to(DEV)).sum() for h, w in zip(ho, probes)).backward()
+    torch.cuda.synchronize()
+    hp = dict(hip.named_parameters())
+    low = []
+    for name, p in ora.named_parameters():
+        if p.grad is None:                      # the frozen DFL projection
+            assert hp[name].grad is None
+            continue
+        gh = hp[name].grad.float().cpu()
+        assert torch.isfinite(gh).all(), name
+        if p.grad.numel() < 64 or p.grad.abs().max().item() < 1e-6:
+            continue
+        cos = torch.nn.functional.cosine_similarity(gh.flatten(), p.grad.flatten(), dim=0).item()
+        if cos < 0.9:
+            low.append(f"{name}: cos {cos:.3f}")
+    assert len(low) <= 8, "bf16 gradients diverge from fp32 autograd:\n" + "\n".join(low[:40])
+
+
+def test_stale_backward_is_refused():
+    ora, hip = build("main", seed=4)
+    x = torch.rand(1, 3, 64, 64).to(DEV)
+    out1 = hip(x, "train")
+    hip(x, "train")                       # overwrites the kept activations of the first forward
+    with pytest.raises(RuntimeError, match="overwritten"):
+        out1[2].sum().backward()
+
+
+def test_native_train_step_matches_torch_loop_fp32():
+    """trainstep.TrainStep (forward -> device loss + gradient -> projector backward -> backward plan -> global-norm clip -> fused SGD over
+    the re-homed flat buckets) against the same two steps done with torch on the oracle: autograd, clip_grad_norm_(10), torch.optim.SGD.
+    Two steps, so that the second one runs on re-prepared weights, moved BatchNorm statistics and a live momentum buffer."""
+    from multitask_bonetumor_yolo_amd.trainstep import TrainStep
+    ora, hip = build("main", seed=6)
+    S, B = 128, 2
+    g = torch.Generator().manual_seed(13)
+    xs = [torch.rand(B, 3, S, S, generator=g) for _ in range(2)]
+    gt_boxes = torch.tensor([[0, 1, 0.5, 0.5, 0.4, 0.3], [1, 0, 0.4, 0.6, 0.5, 0.5], [1, 1, 0.3, 0.3, 0.2, 0.25]])
+    gt_masks = torch.zeros(B, 1, S, S)
+    gt_masks[0, 0, 45:83, 38:90] = 1
+    gt_masks[1, 0, 45:109, 19:83] = 1
+    gt_cls = torch.tensor([1, 0])
+    proj = torch.nn.Conv2d(32, 1, 1)
+    proj_h = torch.nn.Conv2d(32, 1, 1)
+    proj_h.load_state_dict(proj.state_dict())
+    kw = dict(iou_match_thresh=0.05, label_smoothing=0.1)
+    before = {n: p.detach().clone() for n, p in ora.named_parameters()}
+    lr, wd, mom = 0.05, 5e-4, 0.9
+    opt = torch.optim.SGD(list(ora.parameters()) + list(proj.parameters()), lr=lr, momentum=mom, weight_decay=wd)
+    ts = TrainStep(hip, (B, 3, S, S), optimizer="sgd", lr=lr, weight_decay=wd, momentum=mom, clip_norm=10.0, projector=proj_h, **kw)
+    assert ts.n_skip >= 1
+    for step, x in enumerate(xs):
+        opt.zero_grad(set_to_none=True)
+        det_r, (_, _, protos_r), logits_r = ora(x, "train")
+        lr_ = oloss.multitask_loss(det_r, protos_r, logits_r, gt_boxes, gt_masks, gt_cls, proj.weight, proj.bias, img_size=S, nc_det=2, training=True, **kw)
+        lr_[0].backward()
+        total = torch.nn.utils.clip_grad_norm_(list(ora.parameters()) + list(proj.parameters()), 10.0)
+        opt.step()
+        lh = ts.step(x.to(DEV), gt_boxes.to(DEV), gt_masks.to(DEV), gt_cls.to(DEV))
+        torch.cuda.synchronize()
+        assert abs(lh[0].item() - lr_[0].item()) <= 2e-3 * abs(lr_[0].item()), (step, lh[0].item(), lr_[0].item())
+        assert abs(ts.gnorm.item() - total.item()) <= 2e-3 * total.item(), (step, ts.gnorm.item(), total.item())
+    bad = []
+    hp = dict(hip.named_parameters())
+    ref_scale = max((p.detach() - before[n]).abs().max().item() for n, p in ora.named_parameters())
+    for n, p in ora.named_parameters():
+        want = p.detach() - before[n]
+        got = hp[n].detach().float().cpu() - before[n]
+        err = (got - want).abs().max().item()
+        if err > 2e-3 * want.abs().max().item() + 1e-5 * ref_scale:
+            bad.append(f"{n}: err {err:.3e} scale {want.abs().max().item():.3e}")
+    assert not bad, f"{len(bad)} parameters moved differently:\n" + "\n".join(bad[:40])
+    assert (proj_h.weight.detach().cpu() - proj.weight.detach()).abs().max().item() <= 2e-3 * (proj.weight.detach() - 0).abs().max().item()
+    # Segment's cv2 / cv3 / cv4 never reach the loss: untouched, like torch's optimisers leave parameters without a gradient
+    assert torch.equal(hp["segment.cv4.0.0.conv.weight"].detach().cpu(), before["segment.cv4.0.0.conv.weight"])
