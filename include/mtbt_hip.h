@@ -7,8 +7,10 @@
  * names the torch operator call sites (reference file:line) it replaces.  Conventions:
  *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's storage);
  *   - `stream` is a hipStream_t passed as void* (the caller's current stream); launches are
- *     asynchronous, nothing here synchronises, allocates or keeps mutable global state, so the
- *     library is re-entrant (autograd worker threads) and graph-capturable;
+ *     asynchronous, nothing here synchronises, allocates, reads environment variables or keeps mutable
+ *     global state (the only process-wide effect is the idempotent, per-device, one-time opt-in of a few
+ *     kernels to more than 64 KiB of dynamic LDS), so the library is re-entrant (autograd worker
+ *     threads) and graph-capturable;
  *   - activations are NHWC ("channels last"): element (n,y,x,c) of a tensor with C channels lives at
  *     base + n*batch_stride + (y*W + x)*pixel_stride + c   (strides in ELEMENTS);
  *     pixel_stride >= C lets a tensor be a channel slice of a wider buffer (concat-free C2f);
@@ -85,6 +87,10 @@ typedef struct mtbt_conv_args {
                           kernel, bit 26 = keep a 3x3 on the implicit-GEMM kernel, bit 27 = 64-byte K-steps, bits 28-30 = stages */
   void* y2;            /* optional second output (training forward): the PRE-activation conv * scale + shift, addressed and typed
                           like y (no residual added); NULL = not written.  MTBT_OUT_NHWC only. */
+  int32_t policy;      /* 0 = default kernel-selection policy; else 0x100 | bits (bit0 small 1x1 tiles, bit1 64x64 tiles for small k x k,
+                          bit2 direct 3x3 kernel, bit3 row-reuse 3x3 everywhere, bit4 never, bit5 64-channel direct tiles): the host's
+                          A/B knob, passed per call -- the library reads no environment variables and keeps no mutable global state */
+  int32_t debug;       /* ablation bits, honoured by -DMTBT_CONV_ABLATION builds only */
 } mtbt_conv_args;
 
 int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream);

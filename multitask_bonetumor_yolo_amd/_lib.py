@@ -24,6 +24,7 @@ class ConvArgs(C.Structure):
         ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("act", C.c_int32), ("out_mode", C.c_int32), ("tile_hint", C.c_int32), ("y2", C.c_void_p),
+        ("policy", C.c_int32), ("debug", C.c_int32),
     ]
 
 

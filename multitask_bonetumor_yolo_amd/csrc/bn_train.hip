@@ -3,63 +3,70 @@
 // mode for that call (main_model.py:358-359), so their BatchNorms normalise with batch statistics
 // and update running_mean / running_var (momentum, unbiased variance) even under Lightning validation.
 //
-// Deterministic two-pass statistics (sum -> mean, then sum (x-mean)^2 -> biased variance): per-workgroup
-// partials in a workspace, reduced in a fixed order by a finalize kernel; no atomics.  HBM-bound, small tensors.
+// Deterministic statistics: per-workgroup (mean, M2) partials in a workspace, combined exactly in a fixed order; no atomics.
 #include "common.h"
 
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 256;
 
-// PASS 0: partial[b][c] = sum_x ; PASS 1: partial[b][c] = sum (x - mean[c])^2
-template <typename T, int PASS>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, long pixels, int C, const float* __restrict__ mean,
-                                                         float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [G][C]
+// ---- single-pass statistics: every workgroup reduces its ROWS_PER_BLOCK rows to a per-channel (mean_b, M2_b)
+// with sums SHIFTED by the block's first row (no cancellation for |mean| >> sigma); the final kernel combines the blocks exactly
+// (Chan et al.): mean = sum n_b mean_b / N, M2 = sum (M2_b + n_b (mean_b - mean)^2), one WAVE per channel striding over the blocks.
+// One read of x for the statistics instead of two, and no serial loop over thousands of partial rows. ----
+template <typename T>
+__global__ __launch_bounds__(256) void bn_block_stats_kernel(const T* __restrict__ x, long pixels, int C, float* __restrict__ partial /* [blocks][2C] */) {
+  __shared__ float red[256 * 16];
   const int CH8 = C >> 3, G = 256 / CH8;
   const int tid = threadIdx.x, cg = tid % CH8, g = tid / CH8;
   const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
   const long r1 = r0 + ROWS_PER_BLOCK < pixels ? r0 + ROWS_PER_BLOCK : pixels;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mu[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float nb = (float)(r1 - r0);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sh[8];
   if (g < G) {
-    if (PASS == 1) ld8<float>(mean + cg * 8, mu);
+    ld8<T>(x + r0 * C + cg * 8, sh);
     for (long r = r0 + g; r < r1; r += G) {
       float v[8];
       ld8<T>(x + r * C + cg * 8, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[e] - mu[e]; acc[e] += PASS == 0 ? v[e] : d * d; }
+      for (int e = 0; e < 8; ++e) { const float d = v[e] - sh[e]; s[e] += d; q[e] += d * d; }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[g * C + cg * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) { red[(g * CH8 + cg) * 16 + e] = s[e]; red[(g * CH8 + cg) * 16 + 8 + e] = q[e]; }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float s = 0.f;
-    for (int k = 0; k < G; ++k) s += red[k * C + c];
-    partial[(long)blockIdx.x * C + c] = s;
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float ts = 0.f, tq = 0.f;
+      for (int k = 0; k < G; ++k) { ts += red[(k * CH8 + cg) * 16 + e]; tq += red[(k * CH8 + cg) * 16 + 8 + e]; }
+      const float md = ts / nb;                                    // mean of the shifted values
+      partial[(long)blockIdx.x * 2 * C + cg * 8 + e] = sh[e] + md;            // block mean
+      partial[(long)blockIdx.x * 2 * C + C + cg * 8 + e] = tq - ts * md;      // block M2 = sum d^2 - (sum d)^2 / n
+    }
   }
 }
 
-// PASS 0: mean[c] = sum_b partial / pixels.  PASS 1: var[c] (biased) and the running-statistics update.
-template <int PASS>
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, long pixels, float* __restrict__ mean,
-                                   float* __restrict__ var, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * C + c];
-  if (PASS == 0) {
-    mean[c] = s / (float)pixels;
-  } else {
-    const float v = s / (float)pixels;
-    var[c] = v;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
-    if (running_var) {
-      const float unbiased = pixels > 1 ? s / (float)(pixels - 1) : v;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
+__global__ __launch_bounds__(256) void bn_combine_stats_kernel(const float* __restrict__ partial, int nblocks, int C, long pixels, float* __restrict__ mean,
+                                                               float* __restrict__ var, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;                                              // whole waves leave together
+  const long last = pixels - (long)(nblocks - 1) * ROWS_PER_BLOCK;   // rows of the last block
+  float sm = 0.f;
+  for (int b = lane; b < nblocks; b += 64) sm += (b == nblocks - 1 ? (float)last : (float)ROWS_PER_BLOCK) * partial[(long)b * 2 * C + c];
+  const float mu = wave_sum(sm) / (float)pixels;
+  float m2 = 0.f;
+  for (int b = lane; b < nblocks; b += 64) {
+    const float d = partial[(long)b * 2 * C + c] - mu;
+    m2 += partial[(long)b * 2 * C + C + c] + (b == nblocks - 1 ? (float)last : (float)ROWS_PER_BLOCK) * d * d;
+  }
+  m2 = wave_sum(m2);
+  if (lane == 0) {
+    mean[c] = mu;
+    var[c] = m2 / (float)pixels;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (pixels > 1 ? m2 / (float)(pixels - 1) : m2 / (float)pixels);
   }
 }
 
@@ -94,7 +101,7 @@ __global__ void bn_copy_stats_kernel(const float* __restrict__ rm, const float* 
 extern "C" int64_t mtbt_bn_train_workspace_bytes(int64_t pixels, int C) {
   if (pixels <= 0 || C <= 0) return 0;
   const int64_t nb = (pixels + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  return (nb * C + 2 * (int64_t)C) * (int64_t)sizeof(float);
+  return (nb * 2 * C + 2 * (int64_t)C) * (int64_t)sizeof(float);
 }
 
 // General form (training lowering): x dense [pixels][C]; y rows of y_pixel_stride elements (a channel slice of a C2f concat buffer, or
@@ -123,17 +130,12 @@ extern "C" int mtbt_bn_forward_nhwc(const void* x, void* y, int32_t y_pixel_stri
     hipLaunchKernelGGL(bn_copy_stats_kernel, dim3(fb), dim3(256), 0, s, running_mean, running_var, mean, var, C);
   } else {
     if (!workspace || !aligned16(workspace)) return MTBT_EALIGN;
-    if (workspace_bytes < nb * C * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+    if (workspace_bytes < nb * 2 * C * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
     float* partial = reinterpret_cast<float*>(workspace);
-    const size_t lds = (size_t)(256 / CH8) * C * sizeof(float);
-#define BN_STATS(T)                                                                                                            \
-    hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x, (long)pixels, C, nullptr, partial); \
-    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(fb), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, nullptr, nullptr, 0.f); \
-    hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3((unsigned)nb), dim3(256), lds, s, (const T*)x, (long)pixels, C, mean, partial);   \
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(fb), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, running_mean,   \
+    if (dtype == MTBT_F32) hipLaunchKernelGGL(bn_block_stats_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)x, (long)pixels, C, partial);
+    else hipLaunchKernelGGL(bn_block_stats_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)x, (long)pixels, C, partial);
+    hipLaunchKernelGGL(bn_combine_stats_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, running_mean,
                        running_var, momentum);
-    if (dtype == MTBT_F32) { BN_STATS(float) } else { BN_STATS(bf16_t) }
-#undef BN_STATS
   }
   if (dtype == MTBT_F32)
     hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
@@ -151,7 +153,7 @@ extern "C" int mtbt_bn_train_nhwc(const void* x, void* y, const float* gamma, co
   if (!workspace || pixels <= 0 || C <= 0) return MTBT_EINVAL;
   if (workspace_bytes < mtbt_bn_train_workspace_bytes(pixels, C)) return MTBT_EWORKSPACE;
   const long nb = (pixels + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  float* stats = reinterpret_cast<float*>(workspace) + nb * C;
+  float* stats = reinterpret_cast<float*>(workspace) + nb * 2 * C;
   return mtbt_bn_forward_nhwc(x, y, C, gamma, beta, running_mean, running_var, momentum, eps, act, pixels, C, dtype, 0, stats, workspace,
                               workspace_bytes, stream);
 }

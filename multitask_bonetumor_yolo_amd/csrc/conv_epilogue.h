@@ -29,7 +29,9 @@ __device__ __forceinline__ void stage_affine(const ConvP& p, float* aff, int cba
 
 // AddrFn: bool operator()(int j, int row, long& pixel_offset_y, long& pixel_offset_res) -- offsets in elements of the
 // slab pixel (without the channel), false if the pixel is outside the output.
-template <typename T, int TC, int FC, int FP, typename AddrFn>
+// TRAIN = false compiles the training epilogues (y2, MTBT_ACT_D*) out: the direct 3x3 kernels never need them (they are used by the 1x1
+// GEMMs fc1 / fc2-dgrad only) and lost 13 % with the extra code present (tools/conv_ab.py, same box, same run).
+template <typename T, int TC, int FC, int FP, bool TRAIN = true, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr) {
   constexpr int WCH = FC * 16;
@@ -38,6 +40,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
   constexpr int ITER = (16 * C8 + 63) / 64;
   const int lr = lane & 15, lq = lane >> 4;
   const bool has_scale = p.scale != nullptr;
+  // training epilogues keep the PRE-activation in the slab and finish in the row pass: y2 (second output) / MTBT_ACT_D* (multiply by act'(res))
+  const bool deriv = TRAIN && p.act >= MTBT_ACT_DSILU;
+  const bool late_act = TRAIN && (p.y2 != nullptr || deriv);
 #pragma clang loop unroll(full)  // must unroll: a runtime j would put the whole accumulator array in scratch
   for (int j = 0; j < FP; ++j) {
 #pragma unroll
@@ -49,7 +54,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
         const float4 sc = *reinterpret_cast<const float4*>(aff + cl);
         v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
       }
-      v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;   // the activation is applied in pass (2), where the row form also feeds y2
+      v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+      if (!late_act) {   // the usual case: activation here, on the accumulators (wave-uniform branch)
+        v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+      }
       *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
     }
     // wave-local hand-off through LDS (other lanes' data): a compiler barrier is REQUIRED -- the float4 row reads
@@ -66,13 +74,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       const float4 lo = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32);
       const float4 hi = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32 + 16);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const bool deriv = p.act >= MTBT_ACT_DSILU;   // backward epilogue: multiply by act'(res) instead of act() + res
       if (p.vec_ok && ch + 8 <= p.K) {
-        if (p.y2) {   // training forward: keep the pre-activation next to the activated output
+        if (TRAIN && p.y2) {   // training forward: keep the pre-activation next to the activated output
           if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y2) + yoff, v);
           else st8<bf16_t>(reinterpret_cast<bf16_t*>(p.y2) + yoff, v);
-        }
-        if (!deriv) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], p.act);
         }
@@ -89,11 +94,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
         const int lim = (p.out_mode == MTBT_OUT_CONVT2X2) ? (ch / (p.K >> 2) + 1) * (p.K >> 2) : p.K;
         for (int e = 0; e < 8 && ch + e < lim; ++e) {
           float u = v[e];
-          if (p.y2) {
+          if (TRAIN && p.y2) {
             if (p.out_f32) reinterpret_cast<float*>(p.y2)[yoff + e] = u;
             else reinterpret_cast<bf16_t*>(p.y2)[yoff + e] = f2bf(u);
           }
-          if (!deriv) u = act_apply(u, p.act);
+          if (TRAIN && p.y2) u = act_apply(u, p.act);
           if (p.res) {
             const float r = ld_elem<T>(reinterpret_cast<const T*>(p.res) + roff + e);
             u = deriv ? u * act_grad(r, p.act) : u + r;

@@ -1,7 +1,5 @@
 // C entry point of the implicit-GEMM convolution: argument validation, tile / pipeline-depth heuristics and
 // dispatch to the per-dtype translation units (conv_igemm_bf16.hip, conv_igemm_f32.hip; kernel in conv_igemm.inc).
-#include <cstdlib>
-
 #include "common.h"
 #include "conv_params.h"
 
@@ -17,10 +15,8 @@ int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s);
 //     -> 32 KiB of LDS, three or more workgroups per CU hide the load / epilogue latency of the short K loop;
 //   * k x k convolutions (MFMA-bound): 128-pixel tiles with 128-byte K-steps while that still gives >= 2
 //     workgroups per CU, else 64x64 (small pyramid levels, 64-channel head convs).
-static void pick_tile(int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow) {
-  // development knob (A/B inside one process): MTBT_CONV_POLICY bit0 = small 1x1 tiles, bit1 = 64x64 for small k x k
-  const char* pol_s = getenv("MTBT_CONV_POLICY");
-  const int pol = pol_s ? atoi(pol_s) : 7;
+static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow) {
+  // pol (mtbt_conv_args.policy, a development A/B knob the host passes per call): bit0 = small 1x1 tiles, bit1 = 64x64 for small k x k
   int tc;
   if (K % 128 == 0) tc = 128;
   else if (K % 96 == 0) tc = 96;
@@ -90,7 +86,8 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
                (!a->res || a->res_batch_stride == (int64_t)a->Ho * a->Wo * a->res_pixel_stride);
   p.ctiles = 0;
   p.ptiles_per_xcd = 0;
-  { const char* d = getenv("MTBT_CONV_DEBUG"); p.debug = d ? atoi(d) : 0; }
+  p.debug = a->debug;
+  const int pol = (a->policy & 0x100) ? (a->policy & 0xff) : 7;   // 0 = the default policy
   // LDS-DMA addressing: 32-bit byte offsets below 2 GiB relative to (first image of a tile, weight tile row 0)
   if ((double)a->R * a->S > 31) return MTBT_EINVAL;
   if (((long)(128 / (a->Ho * a->Wo) + 2) * a->x_batch_stride + 2L * ((long)a->pad * a->W + a->pad) * a->x_pixel_stride) * es >= 0x7fff0000L) return MTBT_EINVAL;
@@ -109,12 +106,10 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   // 3x3 / stride 1 / pad 1 on 16-aligned maps: direct convolution with an LDS-resident halo tile (conv3x3_direct.inc).
   // tile_hint bit 26 (or MTBT_CONV_POLICY bit 2 cleared) keeps such a conv on the implicit-GEMM kernel (tests, A/B).
   {
-    const char* pol_s = getenv("MTBT_CONV_POLICY");
-    const int pol = pol_s ? atoi(pol_s) : 7;
-    if ((pol & 4) && !((a->tile_hint >> 26) & 1) && a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->H % 16 == 0 &&
+    if ((pol & 4) && !((a->tile_hint >> 26) & 1) && !a->y2 && a->act < MTBT_ACT_DSILU && a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->H % 16 == 0 &&
         a->W % 16 == 0 && a->out_mode == MTBT_OUT_NHWC && a->C % (128 / es) == 0 && a->K > 32 &&
         (long)a->H * a->W * a->x_pixel_stride * es < 0x7fff0000L && (long)128 * 9 * a->C * es < 0x7fff0000L) {
-      int tc = (a->K >= 96 && !getenv("MTBT_DIRECT_TC64")) ? 128 : 64;
+      int tc = (a->K >= 96 && !(pol & 32)) ? 128 : 64;
       // row-reuse variant (conv3x3_rr_kernel): the default for 64-channel tiles (head convs, 6 % faster there; policy bit 4
       // turns that off), everywhere with policy bit 3 / hint bit 25
       if ((pol & 8) || ((a->tile_hint >> 25) & 1) || (tc == 64 && !(pol & 16))) tc |= 0x1000;
@@ -124,7 +119,7 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   int TC, TP, nbuf = 0;
   if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x1ff; TP = a->tile_hint & 0xffff; }
   int narrow = (a->tile_hint >> 27) & 1;  // hint bit 27: force 64-byte K-steps
-  if (!a->tile_hint || !TC || !TP) pick_tile(a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow);
+  if (!a->tile_hint || !TC || !TP) pick_tile(pol, a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow);
   const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));
   if (a->dtype == MTBT_F32) return mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s);

@@ -14,8 +14,6 @@
 //   * all chunks' accumulators stay in registers; the LayerNorm statistics (ConvNeXt conv_dw + norm)
 //     are per-thread partial sums + one LDS transpose-reduce per wave (a wave holds ALL channels of its
 //     16 pixels), two-pass mean/variance, then the normalised pairs are stored straight from registers.
-#include <cstdlib>
-
 #include "common.h"
 #include "conv_dma.h"
 
@@ -68,7 +66,6 @@ __device__ __forceinline__ void wave_sum16(float (&v)[16], float* red, int lane)
 
 constexpr int CC = 128;  // channels per chunk = 64 lanes x 2
 
-static int dbg_env() { const char* d = getenv("MTBT_DW_DEBUG"); return d ? atoi(d) : 0; }  // development ablation bits
 
 // MAXCH = ceil(C / 128) chunks held in registers.  Workgroups are PERSISTENT: each walks a strided list of tiles
 // (XCD-contiguous ranges, so neighbouring tiles' halos meet in one L2); with a single chunk (C <= 128) the taps stay
@@ -367,7 +364,7 @@ int launch_dw(const void* x, const void* w, const float* bias, const float* lnw,
   auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH, XB>;
   if (int rc = mtbt_allow_lds(kern, lds)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, (const T*)x, (const T*)w, bias, lnw, lnb, eps, scale, shift,
-                     act, (T*)y, (T*)raw, (const T*)res, N, H, W, C, dbg_env());
+                     act, (T*)y, (T*)raw, (const T*)res, N, H, W, C, 0 /* ablation bits: development builds only */);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

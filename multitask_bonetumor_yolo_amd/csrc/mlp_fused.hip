@@ -241,7 +241,7 @@ extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const voi
   MlpP p;
   p.t = reinterpret_cast<const bf16_t*>(t); p.w1 = reinterpret_cast<const bf16_t*>(w1); p.b1 = b1;
   p.w2p = reinterpret_cast<const bf16_t*>(w2p); p.M = (int)M;
-  { const char* d = getenv("MTBT_MLP_DEBUG"); p.dbg = d ? atoi(d) : 0; }
+  p.dbg = 0;   // ablation bits: development builds only (the library reads no environment variables)
   ConvP& e = p.ep;
   e = ConvP{};
   p.res = (p.dbg & 16) ? nullptr : reinterpret_cast<const bf16_t*>(res);

@@ -451,12 +451,8 @@ extern "C" int mtbt_nms_batched(const float* boxes, const float* best_score, con
   const int P2 = pow2ceil(A);
   const int keys_in_lds = (long)P2 * 8 <= 128 * 1024 ? 1 : 0;
   const size_t lds = (size_t)NMS_KEPT_LDS * 16 + (keys_in_lds ? (size_t)P2 * 8 : 0);
-  static size_t lds_opted = 0;  // idempotent opt-in to large dynamic LDS; grows monotonically (benign if raced)
-  if (lds > lds_opted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return MTBT_ELAUNCH;
-    lds_opted = lds;
-  }
+  // one-time (per device) opt-in to the LARGEST dynamic LDS this kernel ever asks for: an idempotent driver attribute, not state
+  if (int rc = mtbt_allow_lds(nms_kernel, NMS_KEPT_LDS * 16 + 128 * 1024)) return rc;
   hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), boxes, best_score, best_label, A,
                      conf_th, iou_th, clamp_max, top_k, reinterpret_cast<long long*>(keep_idx), keep_anchor, out_boxes, out_scores,
                      reinterpret_cast<long long*>(out_labels), counts, n_cand, reinterpret_cast<char*>(workspace), per, P2, keys_in_lds);

@@ -139,6 +139,13 @@ class Plan:
         self.pool = Pool(device)
         self.launches: List[Launch] = []
         self.consts = []  # folded weights etc. (kept alive)
+        # development A/B knobs are read ONCE per plan on the host and travel in the argument blocks (the library reads no environment)
+        import os
+        pol = os.environ.get("MTBT_CONV_POLICY")
+        self.conv_policy = (0x100 | (int(pol) & 0xff)) if pol is not None else 0
+        if os.environ.get("MTBT_DIRECT_TC64"):
+            self.conv_policy = 0x100 | ((self.conv_policy & 0xff) if self.conv_policy else 7) | 32
+        self.conv_debug = int(os.environ.get("MTBT_CONV_DEBUG", "0"))
 
     # ---- execution ----
     def run(self, stream: Optional[int] = None, start: int = 0, end: Optional[int] = None, marks=None):
@@ -367,6 +374,7 @@ class Plan:
         a.N, a.H, a.W, a.C, a.K, a.R, a.S = x.N, x.H, x.W, x.C, K, R, S
         a.stride, a.pad, a.Ho, a.Wo = stride, pad, Ho, Wo
         a.dtype, a.out_dtype, a.act, a.out_mode, a.tile_hint = x.code, y.code, act, out_mode, tile_hint
+        a.policy, a.debug = self.conv_policy, self.conv_debug
         flops = 2.0 * x.N * Ho * Wo * K * R * S * x.C
         byts = (x.N * x.H * x.W * x.C + K * R * S * x.C) * ESIZE[x.code] + x.N * Ho * Wo * K * ESIZE[y.code]
         self.launches.append(Launch(self.lib.mtbt_conv2d_nhwc, (C.byref(a),), name, (a, x.buf, w, y.buf, scale, shift, res), flops, byts))

@@ -55,6 +55,7 @@ class TrainStep:
         self.projector.to(dev)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.group = process_group
+        self._host_staged = False
         # ---- re-home the parameters into flat buckets with the gradient arena's layout ----
         self.params, gview, self.n_skip = make_arena(model, dev, UNUSED_BY_THE_LOSS)
         with torch.no_grad():
@@ -66,12 +67,8 @@ class TrainStep:
                 v.copy_(p.data)
                 p.data = v
             if self.world > 1:
-                for b in self.params.buckets:
-                    dist.broadcast(b, src=0, group=process_group)
-                for buf in model.buffers():
-                    dist.broadcast(buf, src=0, group=process_group)
-                for p in self.projector.parameters():
-                    dist.broadcast(p.data, src=0, group=process_group)
+                for t in list(self.params.buckets) + list(model.buffers()) + [p.data for p in self.projector.parameters()]:
+                    self._bcast(t, 0)
         model.__dict__.pop("_train_plans", None)
         self.tp = TrainPlan(model, tuple(batch_shape), dev, code_of(model.compute_dtype), tail_prefixes=UNUSED_BY_THE_LOSS)
         assert [b.numel() for b in self.tp.arena.buckets] == [b.numel() for b in self.params.buckets]
@@ -122,6 +119,14 @@ class TrainStep:
     def step(self, x: torch.Tensor, gt_boxes: torch.Tensor, gt_masks: torch.Tensor, gt_cls: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's shard.  Returns the loss tuple of `_multitask_loss` as an 8-element device tensor view
         (total, seg, box, dfl, cls_det, img_cls, #positives, mean matched IoU) -- no host synchronisation."""
+        loss = self.forward_backward(x, gt_boxes, gt_masks, gt_cls)
+        self._clip_and_update()
+        self.m.__dict__["_bn_epoch"] = self.m.__dict__.get("_bn_epoch", 0) + 1     # inference plans folded the old weights / statistics
+        return loss
+
+    def forward_backward(self, x: torch.Tensor, gt_boxes: torch.Tensor, gt_masks: torch.Tensor, gt_cls: torch.Tensor) -> torch.Tensor:
+        """Forward, loss, backward and (with more than one rank) the gradient exchange: afterwards `self.grads` / `self.pj_grad` hold this
+        step's (averaged) gradients.  No parameter is touched."""
         tp, lib, dev = self.tp, self.lib, self.dev
         tp.run_forward(x)
         nm = self.m.proto_ch
@@ -133,8 +138,6 @@ class TrainStep:
                                             self.pj_grad.data_ptr(), self.pj_grad.data_ptr() + 4 * nm, 0, self.B, self.S // 4, self.S // 4, nm, self.S, self.S,
                                             self.pj_ws.data_ptr(), self.pj_ws.numel() * 4, _s(dev)), "mtbt_projector_backward")
         self._backward_and_exchange()
-        self._clip_and_update()
-        self.m.__dict__["_bn_epoch"] = self.m.__dict__.get("_bn_epoch", 0) + 1     # inference plans folded the old weights / statistics
         return torch.stack(res)
 
     def _backward_and_exchange(self):
@@ -146,8 +149,7 @@ class TrainStep:
         if self.comm is None:
             self.bwd.run(stream=main.cuda_stream)
             for b in live:
-                self.grads.buckets[b].div_(self.world)
-                dist.all_reduce(self.grads.buckets[b], op=dist.ReduceOp.SUM, group=self.group)
+                self._mean_over_ranks(self.grads.buckets[b])
             self._reduce_projector()
             return
         marks = {str(b): [self.ready[b]] for b in live if self.ready[b] >= 0}
@@ -157,14 +159,48 @@ class TrainStep:
             for b in sorted(live, key=lambda k: self.ready[k]):
                 for ev in events.get(str(b), []):
                     self.comm.wait_event(ev)
-                self.grads.buckets[b].div_(self.world)                 # pre-scaled SUM = mean
-                dist.all_reduce(self.grads.buckets[b], op=dist.ReduceOp.SUM, group=self.group)
+                self._mean_over_ranks(self.grads.buckets[b])
         main.wait_stream(self.comm)
         self._reduce_projector()
 
     def _reduce_projector(self):
-        self.pj_grad.div_(self.world)
-        dist.all_reduce(self.pj_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self._mean_over_ranks(self.pj_grad)
+
+    def _mean_over_ranks(self, t: torch.Tensor):
+        """Pre-scaled SUM = mean (what DDP hands the optimiser).  Backend "nccl" is RCCL over xGMI; the "gloo" rehearsal backend (several
+        ranks sharing one GPU in the tests) may lack device-tensor collectives on this build and then stages through the host."""
+        t.div_(self.world)
+        if not self._host_staged:
+            try:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                return
+            except RuntimeError:
+                if dist.get_backend(self.group) != "gloo":
+                    raise
+                self._host_staged = True
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(h)
+
+    def sync_buffers(self, src: int = 0):
+        """Rank `src`'s BatchNorm running statistics to every rank.  (torch DDP broadcasts buffers before EVERY forward; a train-mode
+        forward never reads them, so doing it before validation / checkpointing is equivalent and costs nothing per step.)"""
+        if self.world > 1:
+            for buf in self.m.buffers():
+                self._bcast(buf, src)
+
+    def _bcast(self, t: torch.Tensor, src: int):
+        if not self._host_staged:
+            try:
+                dist.broadcast(t, src=src, group=self.group)
+                return
+            except RuntimeError:
+                if dist.get_backend(self.group) != "gloo":
+                    raise
+                self._host_staged = True
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=self.group)
+        t.copy_(h)
 
     def _clip_and_update(self):
         lib, s = self.lib, _s(self.dev)

@@ -218,3 +218,47 @@ def test_native_train_step_matches_torch_loop_fp32():
     assert (proj_h.weight.detach().cpu() - proj.weight.detach()).abs().max().item() <= 2e-3 * (proj.weight.detach() - 0).abs().max().item()
     # Segment's cv2 / cv3 / cv4 never reach the loss: untouched, like torch's optimisers leave parameters without a gradient
     assert torch.equal(hp["segment.cv4.0.0.conv.weight"].detach().cpu(), before["segment.cv4.0.0.conv.weight"])
+
+
+def test_two_rank_step_equals_averaged_gradients(tmp_path):
+    """BASELINE configs[3] in miniature: two ranks (one process each, `gloo` rehearsal backend on the shared GPU; "nccl" = RCCL on a real node)
+    run `TrainStep.step` on the two halves of a batch with the bucketed all-reduce overlapped with backward.  The parameters they end with must
+    equal those of ONE process that computes the two shards' gradients separately, averages them and applies the same clip + SGD update --
+    twice, so that the second step starts from exchanged weights."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import ddp_worker as W
+    from multitask_bonetumor_yolo_amd.trainstep import TrainStep
+    out = str(tmp_path / "ddp.pt")
+    env = dict(os.environ, MTBT_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "tools", "ddp_worker.py"), out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out, weights_only=True)
+    # ---- the same two steps in one process: per-shard gradients, averaged by hand ----
+    S, per = 128, 2
+    model = W.build_model(torch.device(DEV))
+    torch.manual_seed(3)
+    proj = torch.nn.Conv2d(32, 1, 1)
+    ts = TrainStep(model, (per, 3, S, S), projector=proj, **W.STEP_KW)
+    batch = W.make_batch(S, 2 * per)
+    for step in range(2):
+        acc, accp = None, None
+        for rank in range(2):
+            x, bx, mk, cl = (t.to(DEV) for t in W.shard(batch, rank, per))
+            ts.forward_backward(x, bx, mk, cl)
+            gs = [b.clone() for b in ts.grads.buckets]
+            acc = gs if acc is None else [a + b for a, b in zip(acc, gs)]
+            accp = ts.pj_grad.clone() if accp is None else accp + ts.pj_grad
+        for b, a in zip(ts.grads.buckets, acc):
+            b.copy_(a / 2)
+        ts.pj_grad.copy_(accp / 2)
+        ts._clip_and_update()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got["buckets"], ts.params.buckets)):
+        err = (a - b.cpu()).abs().max().item()
+        assert err <= 1e-5 * (b.abs().max().item() + 1e-6) + 1e-7, f"parameter bucket {i}: {err}"
+    assert (got["proj"] - ts.pj.cpu()).abs().max().item() <= 1e-5
