@@ -205,7 +205,6 @@ def main():
 
     if rank == 0 and args.ab_graph:
         import time
-        keep_graphs = []
         for rnd in range(2):
             for pol in args.ab_graph.split(","):
                 for kv in pol.split("+"):
@@ -221,7 +220,9 @@ def main():
                     g.replay()
                 torch.cuda.synchronize(dev)
                 print(f"graph A/B {pol} round {rnd}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
-                keep_graphs.append(g)  # destroying a captured multi-stream graph mid-process crashed the runtime once: keep them
+                # (round 1 kept every graph alive here after one abort on destruction: the graph outlived the plan whose buffers it
+                #  replays into -- GraphedInference now owns that plan; tests/test_gpu_model.py destroys and re-captures)
+                del g
         for pol in args.ab_graph.split(","):
             for kv in pol.split("+"):
                 os.environ.pop(kv.rpartition("=")[0], None)

@@ -76,7 +76,9 @@ def _copy_params(sd, prefix, dst_mod, sub, label):
 
 @torch.no_grad()
 def load_pretrained_heads(model, detect_ckpt_path: StateSource = None, segment_ckpt_path: StateSource = None):
-    """Same call as the reference's (`main_model.py:400-402`).  Returns {'detect': (copied, total), 'segment': (copied, total)}."""
+    """Same call and RETURN VALUE as the reference's (`main_model.py:400-402`, `:603`): the model itself -- its callers rebind it
+    (`net = load_pretrained_heads(net, ...)`, `main_model.py:645`).  The per-head counts {'detect': (copied, total), 'segment': ...} are
+    left on `model._head_load_report`."""
     report = {"detect": (0, 0), "segment": (0, 0)}
     det_sd = _flat_state(detect_ckpt_path)
     if getattr(model, "detect", None) is None:
@@ -102,7 +104,12 @@ def load_pretrained_heads(model, detect_ckpt_path: StateSource = None, segment_c
             c_tot, t_tot = c_tot + c, t_tot + t
         report["segment"] = (c_tot, t_tot)
         print(f"Segment head         : {c_tot}/{t_tot} tensors copied from {segment_ckpt_path}")
-    return report
+    total_c, total_t = report["detect"][0] + report["segment"][0], report["detect"][1] + report["segment"][1]
+    print(f"\nHead-weight summary  : {total_c}/{total_t} tensors copied overall.")
+    model.__dict__["_head_load_report"] = report
+    if hasattr(model, "mark_weights_updated"):
+        model.mark_weights_updated()
+    return model
 
 
 def strip_lightning_prefix(state_dict: Dict[str, torch.Tensor], prefix: str = "net.") -> Dict[str, torch.Tensor]:

@@ -188,7 +188,13 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
       const int cc = min(CC, C - cb);              // channels in this chunk (multiple of 8)
       const bool active = lane * 2 < cc;
       if (MAXCH > 1 || first) {                    // (one chunk: every later tile was requested during the previous epilogue)
-        __syncthreads();                           // the previous tile's / chunk's readers (and LN scratch users) are done
+        // Restaging barrier = lds_barrier(), NOT a plain __syncthreads(): the DMA below lands through the vector-memory path,
+        // which is not ordered with the LDS queue, so every wave's ds_reads of the previous chunk must have RETURNED
+        // (lgkmcnt(0)) before any wave restages.  A workgroup-scope __syncthreads() does not wait for outstanding LDS
+        // reads, and the compiler may park the FMAs that consume them behind the barrier: the tail of an in-flight read --
+        // lanes 48..63, the last 16-lane pass -- then picks up bytes of the NEXT chunk.  That is the failure the removed
+        // two / three-chunk kernel showed next to MFMA kernels (LDS port contention widens the window); see DESIGN.md 4.
+        lds_barrier();
         stage(tl, cb);
       }
       wait_vm<0>();
@@ -243,12 +249,12 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
     const unsigned rowel = (unsigned)(W * C);
     if (dbg & 4) { if (acc[0][0][0].x == 123.f) y[0] = T(0); if (MAXCH == 1) { __syncthreads(); if (tl + step < t_end) stage(tl + step, 0); } continue; }
     if (MAXCH == 1) {   // one chunk: request the next tile now, it lands while this tile's epilogue runs
-      __syncthreads();  // every wave is done reading the staged tile
+      lds_barrier();    // every wave's reads of the staged tile have returned (see the restaging barrier in chunk())
       if (tl + step < t_end) stage(tl + step, 0);
     }
     if constexpr (LN) {
       // + bias, per-pixel statistics over all C channels (held by this wave), normalise, store
-      if (MAXCH > 1) __syncthreads();  // every wave is done with the staged tile: its LDS is reused for the reductions
+      if (MAXCH > 1) lds_barrier();    // every wave is done with the staged tile: its LDS is reused for the reductions
       float* red = reinterpret_cast<float*>(smem + REDOFF) + wave * (16 * 64 + 16);
       float s[16];  // wave_sum16 reduces 16 values; sub-tiles with fewer pixels leave the rest zero
 #pragma unroll

@@ -17,6 +17,7 @@ class GraphedInference:
         if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError("GraphedInference needs a contiguous fp32 CUDA/HIP batch [B,3,S,S] (it is read in place)")
         self.model, self.x = model, x
+        self._compiled = None             # the lowered plan the captured kernels point into: pool buffers + folded weights
         self.args = (img_size, conf_th, iou_th, top_k, masks)
         self.stream = torch.cuda.Stream(device=x.device)
         self.side = torch.cuda.Stream(device=x.device)   # decode + NMS fork (see _Base.infer_and_detect)
@@ -29,7 +30,22 @@ class GraphedInference:
             # thread_local: with a process group alive, RCCL's watchdog thread may touch the HIP runtime during the capture
             with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                 self.fwd, self.out = self._step()
+            # Keep the plan alive for as long as the graph: the model's plan cache may evict it (weight update, BatchNorm mode flip),
+            # which would hand its buffers back to the caching allocator while the captured kernels still read and write them.
+            self._compiled = self._eval_compile()
+            self._sig = self._compiled.sig
         torch.cuda.current_stream(x.device).wait_stream(self.stream)
+
+    def _eval_compile(self):
+        heads = [h for h in (getattr(self.model, "detect", None), self.model.segment) if h is not None]
+        flags = [h.training for h in heads]
+        try:
+            for h in heads:
+                h.eval()
+            return self.model.compile(self.x)
+        finally:
+            for h, f in zip(heads, flags):
+                h.training = f
 
     def _step(self):
         img_size, conf_th, iou_th, top_k, masks = self.args
@@ -37,5 +53,14 @@ class GraphedInference:
                                            own_outputs=False)   # static outputs: a replay overwrites them anyway
 
     def replay(self):
+        bn_modes = self._compiled_modes()
+        if self.model._weights_sig(bn_modes) != self._sig:
+            raise RuntimeError("GraphedInference: the model's weights / BatchNorm statistics changed since the capture (the graph replays "
+                               "kernels over the OLD folded weights): build a new GraphedInference")
         self.graph.replay()
         return self.out
+
+    def _compiled_modes(self):
+        import torch.nn as nn
+        heads = {id(m) for h in (getattr(self.model, "detect", None), self.model.segment) if h is not None for m in h.modules()}
+        return tuple((False if id(m) in heads else m.training) for m in self.model.modules() if isinstance(m, nn.BatchNorm2d))

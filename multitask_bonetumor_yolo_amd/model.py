@@ -558,9 +558,23 @@ class _Base(nn.Module):
         self.compute_dtype = dtype
         return self
 
-    def _weights_sig(self):
-        return (sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers()),
-                tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)), self.__dict__.get("_bn_epoch", 0))
+    def _weights_sig(self, bn_modes=None):
+        """What a lowered plan's FOLDED constants depend on: parameter / buffer versions (torch's in-place counters), the epoch counter
+        that raw-pointer parameter updates bump (`mark_weights_updated`: the fused optimisers, checkpoint loaders), storage identity
+        (a re-homed or re-assigned `.data`) and, for the BatchNorms this plan runs in EVAL mode, their running statistics (a
+        BatchNorm on batch statistics folds nothing, so a train-mode call never invalidates its own plan)."""
+        ver = sum(p._version for p in self.parameters()) + sum(p.data_ptr() & 0xffff for p in self.parameters())
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        for m, tr in zip(bns, bn_modes if bn_modes is not None else [m.training for m in bns]):
+            if not tr:      # eval-mode BatchNorm: this plan FOLDED its running statistics (`_mtbt_epoch`: in-kernel updates of them)
+                ver += m.running_mean._version + m.running_var._version + m.__dict__.get("_mtbt_epoch", 0)
+        return (ver, self.__dict__.get("_w_epoch", 0))
+
+    def mark_weights_updated(self):
+        """Call after changing parameters or buffers through raw pointers (in place, outside torch's version counters): plans that
+        folded the old values re-lower on their next use."""
+        self.__dict__["_w_epoch"] = self.__dict__.get("_w_epoch", 0) + 1
+        return self
 
     def _heads(self):
         raise NotImplementedError
@@ -579,9 +593,14 @@ class _Base(nn.Module):
             raise RuntimeError("ConvNeXtBiFPNYOLO (HIP) needs CUDA/HIP tensors on an MI355X; there is no CPU path")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"expected [B,3,S,S] with S a multiple of 32, got {tuple(x.shape)}")
-        key = (tuple(x.shape), self.compute_dtype, x.device.index)
-        sig = self._weights_sig()
+        # one plan per BatchNorm-mode tuple: alternating forward(x, "infer") and forward(x, "train") (validation: heads on batch
+        # statistics) no longer evict each other, and a train-mode call does not invalidate its own plan
+        bn_modes = tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        key = (tuple(x.shape), self.compute_dtype, x.device.index, bn_modes)
+        sig = self._weights_sig(bn_modes)
         cache = self.__dict__.setdefault("_plans", {})
+        if len(cache) > 8:                                # bounded: stale (shape, mode) plans hold buffer pools
+            cache.pop(next(iter(cache)))
         c = cache.get(key)
         if c is not None and c.sig == sig:
             return c
@@ -671,7 +690,7 @@ class _Base(nn.Module):
             for bn in c.train_bns:
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
-            self.__dict__["_bn_epoch"] = self.__dict__.get("_bn_epoch", 0) + 1  # invalidates plans that folded the old statistics
+                bn.__dict__["_mtbt_epoch"] = bn.__dict__.get("_mtbt_epoch", 0) + 1   # invalidates plans that folded its old statistics
 
     # decoded `[B, 4+nc(+nm), A]` tensor of Detect/Segment eval (ultralytics `_inference`), from raw maps
     def _preds_cat(self, maps: List[Act], head: Detect, mc: torch.Tensor = None):

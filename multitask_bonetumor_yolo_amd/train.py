@@ -891,6 +891,8 @@ class TrainPlan:
         self.generation += 1
         if self.train_bns:
             torch._foreach_add_([bn.num_batches_tracked for bn in self.train_bns if bn.num_batches_tracked is not None], 1)
+            for bn in self.train_bns:                        # the kernels rewrote running_mean / running_var: plans that folded them are stale
+                bn.__dict__["_mtbt_epoch"] = bn.__dict__.get("_mtbt_epoch", 0) + 1
 
     def run_backward(self, active: Sequence[str]):
         plan = self.backward_plan(active)

@@ -121,7 +121,7 @@ class TrainStep:
         (total, seg, box, dfl, cls_det, img_cls, #positives, mean matched IoU) -- no host synchronisation."""
         loss = self.forward_backward(x, gt_boxes, gt_masks, gt_cls)
         self._clip_and_update()
-        self.m.__dict__["_bn_epoch"] = self.m.__dict__.get("_bn_epoch", 0) + 1     # inference plans folded the old weights / statistics
+        self.m.mark_weights_updated()                      # inference plans folded the old weights
         return loss
 
     def forward_backward(self, x: torch.Tensor, gt_boxes: torch.Tensor, gt_masks: torch.Tensor, gt_cls: torch.Tensor) -> torch.Tensor:

@@ -180,7 +180,9 @@ def test_load_pretrained_heads_from_flat_state_dict(tmp_path, capsys):
     torch.save(sd_seg, path)
     m = ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)
     bn_before = m.detect.cv2[0][0].bn.running_var.clone()
-    rep = load_pretrained_heads(m, detect_ckpt_path=sd_det, segment_ckpt_path=str(path))
+    ret = load_pretrained_heads(m, detect_ckpt_path=sd_det, segment_ckpt_path=str(path))
+    assert ret is m                                                       # the reference returns the model; callers rebind it (main_model.py:603, :645)
+    rep = m._head_load_report
     n_det, n_seg = len(list(m.detect.named_parameters())), len(list(m.segment.named_parameters()))
     # (the reference walks Segment as cv4, proto, cv2, cv3 -- `dfl.conv.weight` is not part of its Segment report)
     assert rep["detect"] == (n_det, n_det) and rep["segment"] == (n_seg - 1, n_seg - 1)
@@ -188,8 +190,9 @@ def test_load_pretrained_heads_from_flat_state_dict(tmp_path, capsys):
     assert torch.equal(m.detect.cv2[0][0].bn.running_var, bn_before)     # buffers untouched, like named_parameters() in the reference
     out = capsys.readouterr().out
     assert f"Detect head          : {n_det}/{n_det} tensors copied" in out and "Segment head" in out
+    assert f"Head-weight summary  : {n_det + n_seg - 1}/{n_det + n_seg - 1} tensors copied overall." in out
     # class-count mismatch: only the nc-dependent tensors are skipped
-    rep2 = load_pretrained_heads(ConvNeXtBiFPNYOLO(3, 2, pretrained_backbone=False), detect_ckpt_path=sd_det)
+    rep2 = load_pretrained_heads(ConvNeXtBiFPNYOLO(3, 2, pretrained_backbone=False), detect_ckpt_path=sd_det)._head_load_report
     assert rep2["detect"][0] == n_det - 6 and "Shape mismatch" in capsys.readouterr().out
     # a pickled object is refused with instructions, never unpickled
     import pickle

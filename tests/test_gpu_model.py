@@ -355,3 +355,36 @@ def test_concurrent_lanes_are_deterministic_at_full_size(monkeypatch):
         g.replay()
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(ref, snap(g.fwd, g.out)))
+
+
+def test_graph_outlives_plan_eviction_and_refuses_stale_weights():
+    """a captured graph points into its launch plan's buffers and folded weights.  The GraphedInference object keeps that plan
+    alive when the model's plan cache drops it, refuses to replay after the weights changed, and a graph can be destroyed and a new one
+    captured in the same process."""
+    from multitask_bonetumor_yolo_amd import init_synthetic_
+    from multitask_bonetumor_yolo_amd.graphed import GraphedInference
+    torch.manual_seed(6)
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.rand(2, 3, 128, 128, device=DEV)
+    g = GraphedInference(hip, x, 128)
+    ref = [t.clone() for t in (g.replay()["keep_idx"], g.fwd["segment_protos"][2])]
+    torch.cuda.synchronize()
+    hip.__dict__.pop("_plans")                       # what a signature change does to the cache entry
+    junk = [torch.randn(1 << 20, device=DEV) for _ in range(64)]      # would land in the freed pool if the plan had been released
+    out = g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["keep_idx"], ref[0]) and torch.equal(g.fwd["segment_protos"][2], ref[1])
+    del junk
+    with torch.no_grad():
+        hip.cls_fc.weight.mul_(1.5)                   # an in-place update torch's version counter sees
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        g.replay()
+    del g                                            # destroy the captured (multi-stream) graph ...
+    torch.cuda.synchronize()
+    g2 = GraphedInference(hip, x, 128)               # ... and capture again in the same process
+    out2 = g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out2["keep_idx"], ref[0])      # (cls_fc does not feed the boxes)
+    hip.mark_weights_updated()                        # what raw-pointer updates (fused optimiser) must call
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        g2.replay()
