@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (infer) / 32 (train)")
     ap.add_argument("--img", type=int, default=IMG, help="image side (default 640 = the benchmark configuration; 1280 = BASELINE configs[4]'s shape)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="f16 = BASELINE configs[4]'s arithmetic (inference only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the ~220 launches of a step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
@@ -169,7 +169,7 @@ def main():
 
     torch.manual_seed(0)
     model = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
-    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype])
     B = args.batch
     globals()["IMG"] = args.img
     x = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(rank)).to(dev)  # resident in HBM
@@ -277,13 +277,13 @@ def main():
         # by tools/summarize_pmc.py with the guide's gfx950 corrections; bench.py cannot run the profiler on itself
         traffic, traffic_src = None, None
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            if name.endswith("_traffic.json") and args.dtype == "bf16":
+            if name.endswith("_traffic.json") and args.dtype == "bf16" and (B, IMG) == (BATCH_PER_GPU, 640):
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic, traffic_src = round(json.load(f)["traffic_bytes_per_launch"]), "profiles/" + name
                 break
         conv_bytes = sum(l.bytes for l, _ in conv)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "f16") else 157.3
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_direct_kernel + conv3x3_rr_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv_bytes / len(conv)),
@@ -295,7 +295,7 @@ def main():
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if (B, IMG) == (BATCH_PER_GPU, 640) else 'side measurement'}: batch-{B}/GPU {IMG}x{IMG} multitask inference (ConvNeXt-T + C2f-BiFPN + Detect/Segment/cls) "
+            "config": {"workload": f"{'configs[1]' if (B, IMG, args.dtype) == (BATCH_PER_GPU, 640, 'bf16') else ('configs[4]' if (B, IMG, args.dtype) == (64, 1280, 'f16') else 'side measurement')}: batch-{B}/GPU {IMG}x{IMG} multitask inference (ConvNeXt-T + C2f-BiFPN + Detect/Segment/cls) "
                                    f"+ decode + per-image NMS(top-100) + mask assembly; random-init weights",
                        "batch_per_gpu": B, "img": IMG, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "kept_boxes_per_image": float(res["counts"].float().mean().item())},

@@ -34,6 +34,8 @@ extern "C" {
 /* storage / arithmetic types */
 #define MTBT_F32 0
 #define MTBT_BF16 1
+#define MTBT_F16 2 /* IEEE binary16 storage, v_mfma_f32_16x16x32_f16, fp32 accumulate, SATURATING stores (+-65504): the inference
+                      kernels (conv, depthwise, stem, LayerNorm, fusion, GAP+FC, fused MLP, casts) -- BASELINE configs[4] */
 
 /* fused epilogue activations */
 #define MTBT_ACT_NONE 0
@@ -79,7 +81,7 @@ typedef struct mtbt_conv_args {
   int32_t R, S;        /* filter */
   int32_t stride, pad; /* same in y and x */
   int32_t Ho, Wo;      /* conv output size (before the CONVT scatter) */
-  int32_t dtype;       /* MTBT_F32 | MTBT_BF16: x, w, res */
+  int32_t dtype;       /* MTBT_F32 | MTBT_BF16 | MTBT_F16: x, w, res */
   int32_t out_dtype;   /* dtype of y: == dtype, or MTBT_F32 */
   int32_t act;         /* MTBT_ACT_* */
   int32_t out_mode;    /* MTBT_OUT_* */
@@ -285,6 +287,9 @@ int mtbt_multitask_loss_grad(const mtbt_loss_args* a, float* const* d_map, const
  * inside every group of 32 hidden units: slot 8g+j holds hidden 4g+j (j < 4) or 16+4g+(j-4) (j >= 4), g = 0..3. */
 int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
                             const float* b2, void* y, int64_t M, int D, void* stream);
+/* the same with the 16-bit storage type given: MTBT_BF16 or MTBT_F16 */
+int mtbt_convnext_mlp_fused_dt(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
+                               const float* b2, void* y, int64_t M, int D, int dtype, void* stream);
 
 /* Pairwise IoU of xyxy boxes (running_main_v3.py:71-97, `batch_bbox_iou`): out[i][j] = inter / (area1_i + area2_j - inter + eps),
  * inter = clamp(min(x2)-max(x1), 0) * clamp(min(y2)-max(y1), 0); fp32, the reference's operation order without FMA

@@ -6,9 +6,12 @@
 #include "mtbt_hip.h"
 
 typedef uint16_t bf16_t;  // storage type of a bf16 element
+struct f16_t { uint16_t v; };  // storage type of an IEEE binary16 element (a distinct type: the kernels dispatch on it)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
@@ -18,15 +21,37 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// fp16 <-> fp32.  Stores SATURATE at +-65504 instead of overflowing to infinity (BASELINE configs[4]: "fp16 MFMA conv path"): an
+// activation beyond the binary16 range would otherwise poison every later layer; NaN stays NaN.
+__device__ __forceinline__ float h2f(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.v); }
+__device__ __forceinline__ uint16_t f2h_bits(float f) {
+  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ f16_t f2h(float f) { return f16_t{f2h_bits(f)}; }
+__device__ __forceinline__ uint32_t pk_h2(float a, float b) {   // two floats -> packed half pair (one v_cvt_pkrtz-free RNE convert each)
+  return (uint32_t)f2h_bits(a) | ((uint32_t)f2h_bits(b) << 16);
+}
+__device__ __forceinline__ float h_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float h_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+
+// the 16-bit type a kernel templated on T stores when its output is not fp32 (T itself; bf16_t stands in for the dead T = float branch)
+template <typename T> struct half_of { typedef T type; };
+template <> struct half_of<float> { typedef bf16_t type; };
+
 template <typename T> __device__ __forceinline__ float ld_elem(const T* p);
 template <> __device__ __forceinline__ float ld_elem<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld_elem<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <> __device__ __forceinline__ float ld_elem<f16_t>(const f16_t* p) { return h2f(*p); }
 
 template <typename T> __device__ __forceinline__ void st_elem(T* p, float v);
 template <> __device__ __forceinline__ void st_elem<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_elem<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
-// 8 consecutive elements <-> 8 floats (two 16-B accesses for f32, one for bf16)
+template <> __device__ __forceinline__ void st_elem<f16_t>(f16_t* p, float v) { *p = f2h(v); }
+
+// 8 consecutive elements <-> 8 floats (two 16-B accesses for f32, one for bf16 / fp16)
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
 template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
   float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -38,6 +63,11 @@ template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (
   v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
   v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
   v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void ld8<f16_t>(const f16_t* p, float (&v)[8]) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  v[0] = h_lo(u.x); v[1] = h_hi(u.x); v[2] = h_lo(u.y); v[3] = h_hi(u.y);
+  v[4] = h_lo(u.z); v[5] = h_hi(u.z); v[6] = h_lo(u.w); v[7] = h_hi(u.w);
 }
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
@@ -52,6 +82,22 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (
   u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
   *reinterpret_cast<uint4*>(p) = u;
 }
+
+template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = pk_h2(v[0], v[1]); u.y = pk_h2(v[2], v[3]); u.z = pk_h2(v[4], v[5]); u.w = pk_h2(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+// one 16x16x32 MFMA on 8-element fragments held as raw 16-byte words: bf16 or fp16 by the storage type
+template <typename T> __device__ __forceinline__ f32x4 mfma_16x16x32(uint4 a, uint4 b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<bf16_t>(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<f16_t>(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma_16x16x32<float>(uint4, uint4, f32x4 c) { return c; }   // (never called: the f32 path uses 16x16x4)
 
 // Epilogue activations.  These run on every conv output, so they use the hardware exp2 / rcp
 // (v_exp_f32, v_rcp_f32: ~1 ulp) instead of libm: absolute error <= ~3e-7 of the libm value, three

@@ -38,6 +38,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
   constexpr int PITCH = WCH * 4 + 16;
   constexpr int C8 = WCH / 8;
   constexpr int ITER = (16 * C8 + 63) / 64;
+  typedef typename half_of<T>::type HT;   // 16-bit output element (bf16 / fp16) when the output is not fp32
   const int lr = lane & 15, lq = lane >> 4;
   const bool has_scale = p.scale != nullptr;
   // training epilogues keep the PRE-activation in the slab and finish in the row pass: y2 (second output) / MTBT_ACT_D* (multiply by act'(res))
@@ -77,7 +78,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       if (p.vec_ok && ch + 8 <= p.K) {
         if (TRAIN && p.y2) {   // training forward: keep the pre-activation next to the activated output
           if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y2) + yoff, v);
-          else st8<bf16_t>(reinterpret_cast<bf16_t*>(p.y2) + yoff, v);
+          else st8<HT>(reinterpret_cast<HT*>(p.y2) + yoff, v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], p.act);
         }
@@ -88,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
           for (int e = 0; e < 8; ++e) v[e] = deriv ? v[e] * act_grad(r[e], p.act) : v[e] + r[e];
         }
         if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y) + yoff, v);
-        else st8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + yoff, v);
+        else st8<HT>(reinterpret_cast<HT*>(p.y) + yoff, v);
       } else {
         // unaligned / ragged channel tail (e.g. the nc-channel class conv, the 66-wide detect map)
         const int lim = (p.out_mode == MTBT_OUT_CONVT2X2) ? (ch / (p.K >> 2) + 1) * (p.K >> 2) : p.K;
@@ -96,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
           float u = v[e];
           if (TRAIN && p.y2) {
             if (p.out_f32) reinterpret_cast<float*>(p.y2)[yoff + e] = u;
-            else reinterpret_cast<bf16_t*>(p.y2)[yoff + e] = f2bf(u);
+            else st_elem<HT>(reinterpret_cast<HT*>(p.y2) + yoff + e, u);
           }
           if (TRAIN && p.y2) u = act_apply(u, p.act);
           if (p.res) {
@@ -104,7 +105,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
             u = deriv ? u * act_grad(r, p.act) : u + r;
           }
           if (p.out_f32) reinterpret_cast<float*>(p.y)[yoff + e] = u;
-          else reinterpret_cast<bf16_t*>(p.y)[yoff + e] = f2bf(u);
+          else st_elem<HT>(reinterpret_cast<HT*>(p.y) + yoff + e, u);
         }
       }
     }

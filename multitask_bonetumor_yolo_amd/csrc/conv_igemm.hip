@@ -7,6 +7,8 @@ int mtbt_conv_dispatch_bf16(const ConvP& p, int TC, int TP, int wide, int nbuf, 
 int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
 int mtbt_conv3x3_direct_bf16(const ConvP& p, int TC, hipStream_t s);
 int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s);
+int mtbt_conv_dispatch_f16(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
+int mtbt_conv3x3_direct_f16(const ConvP& p, int TC, hipStream_t s);
 
 // Tile heuristics, from the sweep in tools/conv_tune.py on the shapes of the 640x640 batch-16 forward
 // (numbers in DESIGN.md):
@@ -57,7 +59,7 @@ static int pick_nbuf(int TC, int TP, int BKB, int nsteps) {
 
 extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   if (!a || !a->x || !a->w || !a->y) return MTBT_EINVAL;
-  if (a->dtype != MTBT_F32 && a->dtype != MTBT_BF16) return MTBT_EINVAL;
+  if (a->dtype != MTBT_F32 && a->dtype != MTBT_BF16 && a->dtype != MTBT_F16) return MTBT_EINVAL;
   if (a->out_dtype != a->dtype && a->out_dtype != MTBT_F32) return MTBT_EINVAL;
   if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->C <= 0 || a->K <= 0 || a->R <= 0 || a->S <= 0 || a->stride <= 0 || a->pad < 0)
     return MTBT_EINVAL;
@@ -113,7 +115,7 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
       // row-reuse variant (conv3x3_rr_kernel): the default for 64-channel tiles (head convs, 6 % faster there; policy bit 4
       // turns that off), everywhere with policy bit 3 / hint bit 25
       if ((pol & 8) || ((a->tile_hint >> 25) & 1) || (tc == 64 && !(pol & 16))) tc |= 0x1000;
-      return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s);
+      return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : (a->dtype == MTBT_F16 ? mtbt_conv3x3_direct_f16(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s));
     }
   }
   int TC, TP, nbuf = 0;
@@ -123,5 +125,6 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));
   if (a->dtype == MTBT_F32) return mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s);
+  if (a->dtype == MTBT_F16) return mtbt_conv_dispatch_f16(p, TC, TP, wide, nbuf, s);
   return mtbt_conv_dispatch_bf16(p, TC, TP, wide, nbuf, s);
 }

@@ -64,6 +64,14 @@ __device__ __forceinline__ void wave_sum16(float (&v)[16], float* red, int lane)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // totals read before the region is written again
 }
 
+template <> struct Pair<f16_t> {
+  static __device__ __forceinline__ f32x2 ld(const void* p) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    return f32x2{h_lo(u), h_hi(u)};
+  }
+  static __device__ __forceinline__ void st(f16_t* p, f32x2 v) { *reinterpret_cast<uint32_t*>(p) = pk_h2(v.x, v.y); }
+};
+
 constexpr int CC = 128;  // channels per chunk = 64 lanes x 2
 
 
@@ -247,7 +255,7 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
     const int oy0 = ty0 + sy * YB, ox0 = tx0 + sx * XB;
     T* yt = y + (((long)n * H + oy0) * W + ox0) * C;     // wave-uniform base; per-lane offsets below stay 32-bit
     const unsigned rowel = (unsigned)(W * C);
-    if (dbg & 4) { if (acc[0][0][0].x == 123.f) y[0] = T(0); if (MAXCH == 1) { __syncthreads(); if (tl + step < t_end) stage(tl + step, 0); } continue; }
+    if (dbg & 4) { if (acc[0][0][0].x == 123.f) st_elem<T>(y, 0.f); if (MAXCH == 1) { __syncthreads(); if (tl + step < t_end) stage(tl + step, 0); } continue; }
     if (MAXCH == 1) {   // one chunk: request the next tile now, it lands while this tile's epilogue runs
       lds_barrier();    // every wave's reads of the staged tile have returned (see the restaging barrier in chunk())
       if (tl + step < t_end) stage(tl + step, 0);
@@ -408,6 +416,9 @@ static int dwconv_entry(const void* x, const void* w, const float* bias, const f
   if (dtype == MTBT_BF16) {
     if (ksize == 7) return ln ? dispatch_chunks<bf16_t, 7, true, 4, 16>(DW_ARGS) : dispatch_chunks<bf16_t, 7, false, 4, 16>(DW_ARGS);
     return ln ? dispatch_chunks<bf16_t, 3, true, 4, 16>(DW_ARGS) : dispatch_chunks<bf16_t, 3, false, 4, 16>(DW_ARGS);
+  } else if (dtype == MTBT_F16) {
+    if (ksize == 7) return ln ? dispatch_chunks<f16_t, 7, true, 4, 16>(DW_ARGS) : dispatch_chunks<f16_t, 7, false, 4, 16>(DW_ARGS);
+    return ln ? dispatch_chunks<f16_t, 3, true, 4, 16>(DW_ARGS) : dispatch_chunks<f16_t, 3, false, 4, 16>(DW_ARGS);
   } else if (dtype == MTBT_F32) {
     if (ksize == 7) return ln ? dispatch_chunks<float, 7, true, 4, 8>(DW_ARGS) : dispatch_chunks<float, 7, false, 4, 8>(DW_ARGS);
     return ln ? dispatch_chunks<float, 3, true, 4, 8>(DW_ARGS) : dispatch_chunks<float, 3, false, 4, 8>(DW_ARGS);

@@ -48,7 +48,17 @@ struct MlpP {
   ConvP ep;            // epilogue view: shift = b2', res, y, K = D
 };
 
-template <int D, int FP, int WPS>
+// HT = bf16_t or f16_t: the MFMA flavour and the fp32 <-> 16-bit conversions (everything else is byte-identical)
+template <typename HT> __device__ __forceinline__ uint32_t pk2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pk2<bf16_t>(float a, float b) { return pk_bf16(a, b); }
+template <> __device__ __forceinline__ uint32_t pk2<f16_t>(float a, float b) { return pk_h2(a, b); }
+template <typename HT> __device__ __forceinline__ f32x4 unpack4(uint2 r);
+template <> __device__ __forceinline__ f32x4 unpack4<bf16_t>(uint2 r) {
+  return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+template <> __device__ __forceinline__ f32x4 unpack4<f16_t>(uint2 r) { return f32x4{h_lo(r.x), h_hi(r.x), h_lo(r.y), h_hi(r.y)}; }
+
+template <int D, int FP, int WPS, typename HT>
 __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   constexpr int KS1 = D / 32;            // k-steps of GEMM1
   constexpr int FC = D / 16;             // output-channel fragments of GEMM2
@@ -124,8 +134,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
     for (int i = 0; i < FC; ++i) {
       uint2 r = uint2{0u, 0u};
       if (p.res && pix < p.M) r = *reinterpret_cast<const uint2*>(p.res + (long)pix * D + i * 16 + lq * 4);
-      acc2[i][f] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-                         __uint_as_float(r.y & 0xffff0000u)};
+      acc2[i][f] = unpack4<HT>(r);
     }
   }
 
@@ -163,8 +172,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
         const uint4 wb = *reinterpret_cast<const uint4*>(st + a1off[ks] + 1024);
 #pragma unroll
         for (int f = 0; f < FP; ++f) {
-          h[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, tf[f][ks]), h[0][f], 0, 0, 0);
-          h[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, tf[f][ks]), h[1][f], 0, 0, 0);
+          h[0][f] = mfma_16x16x32<HT>(wa, tf[f][ks], h[0][f]);
+          h[1][f] = mfma_16x16x32<HT>(wb, tf[f][ks], h[1][f]);
         }
       }
       // bias + GELU + bf16: the lane's 4 + 4 hidden units of pixel lr are GEMM2's B fragment (see top)
@@ -177,8 +186,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
         const float c0 = G_(h[1][f][0] + bb.x), c1 = G_(h[1][f][1] + bb.y);
         const float c2 = G_(h[1][f][2] + bb.z), c3 = G_(h[1][f][3] + bb.w);
 #undef G_
-        hb[f].x = pk_bf16(a0, a1); hb[f].y = pk_bf16(a2, a3);
-        hb[f].z = pk_bf16(c0, c1); hb[f].w = pk_bf16(c2, c3);
+        hb[f].x = pk2<HT>(a0, a1); hb[f].y = pk2<HT>(a2, a3);
+        hb[f].z = pk2<HT>(c0, c1); hb[f].w = pk2<HT>(c2, c3);
       }
       // GEMM2: y[D][PW] += W2'_j . hidden
       if (!(p.dbg & 2))
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
         const uint4 w2 = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
 #pragma unroll
         for (int f = 0; f < FP; ++f)
-          acc2[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), __builtin_bit_cast(bf16x8, hb[f]), acc2[i][f], 0, 0, 0);
+          acc2[i][f] = mfma_16x16x32<HT>(w2, hb[f], acc2[i][f]);
       }
     }
   }
@@ -206,14 +215,14 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
       const int pix = pbase + f * 16 + lr;
       if (pix >= p.M) continue;
       uint2 o;
-      o.x = pk_bf16(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
-      o.y = pk_bf16(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
+      o.x = pk2<HT>(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
+      o.y = pk2<HT>(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
       *reinterpret_cast<uint2*>(yb + (long)pix * D + i * 16 + lq * 4) = o;
     }
   }
 }
 
-template <int D, int FP, int WPS>
+template <int D, int FP, int WPS, typename HT>
 int launch_mlp(const MlpP& p, hipStream_t s) {
   constexpr int P = 4 * FP * 16;
   constexpr int STAGE = 32 * D * 2 + D * 64;
@@ -221,8 +230,8 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   const long blocks = ((long)p.M + P - 1) / P;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS>, lds)) return rc;
-  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS, HT>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS, HT>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -232,9 +241,10 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
 // t, res, y: dense [M][D] bf16 (y may not alias t; it may alias res only if equal pixel-for-pixel, which the in-place
 // residual stream does not need).  w1 [4D][D] bf16, b1 [4D] f32, w2p [D][4D] bf16 with the per-32 hidden permutation,
 // b2 [D] f32.  D in {96, 192}.
-extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
-                                       const float* b2, void* y, int64_t M, int D, void* stream) {
+static int mlp_entry(const void* t, const void* res, const void* w1, const float* b1, const void* w2p, const float* b2, void* y, int64_t M, int D,
+                     int dtype, void* stream) {
   if (!t || !w1 || !b1 || !w2p || !b2 || !y || M <= 0 || M > 0x7fffff00L) return MTBT_EINVAL;
+  if (dtype != MTBT_BF16 && dtype != MTBT_F16) return MTBT_EINVAL;
   if (D != 96 && D != 192) return MTBT_EINVAL;
   if (!aligned16(t) || !aligned16(w1) || !aligned16(w2p) || !aligned16(y) || !aligned16(b1) || (res && !aligned16(res))) return MTBT_EALIGN;
   if ((long)4 * D * D * 2 >= 0x7fff0000L) return MTBT_EINVAL;
@@ -252,5 +262,17 @@ extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const voi
   // pixels per wave / waves per SIMD, measured (tools/mlp_probe.py): d = 96: 2 x 16 pixels at 4 waves per SIMD 100 us,
   // 3 x 16 at 3: 116, 4 x 16 at 2: 139 -- the kernel's skeleton (input / residual loads, stores) is latency-bound, so
   // residency beats the larger register tile; d = 192: 2 x 16 at 2: 110 us, 1 x 16 at 4: 125 (LDS-read bound).
-  return D == 96 ? launch_mlp<96, 2, 4>(p, s) : launch_mlp<192, 2, 2>(p, s);
+  if (dtype == MTBT_F16) return D == 96 ? launch_mlp<96, 2, 4, f16_t>(p, s) : launch_mlp<192, 2, 2, f16_t>(p, s);
+  return D == 96 ? launch_mlp<96, 2, 4, bf16_t>(p, s) : launch_mlp<192, 2, 2, bf16_t>(p, s);
+}
+
+extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
+                                       const float* b2, void* y, int64_t M, int D, void* stream) {
+  return mlp_entry(t, res, w1, b1, w2p, b2, y, M, D, MTBT_BF16, stream);
+}
+
+// the same with the storage / MFMA type given: MTBT_BF16 or MTBT_F16 (BASELINE configs[4])
+extern "C" int mtbt_convnext_mlp_fused_dt(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
+                                          const float* b2, void* y, int64_t M, int D, int dtype, void* stream) {
+  return mlp_entry(t, res, w1, b1, w2p, b2, y, M, D, dtype, stream);
 }

@@ -76,24 +76,32 @@ __global__ void stem_kernel(const float* __restrict__ x, const float* __restrict
 // wave's whole grid-stride loop.  LayerNorm2d: a pixel's channels sit in the 4 lanes {n, n+16, n+32, n+48}
 // x 4 registers x Cout/16 fragments, so two xor-shuffles finish each reduction.
 // ------------------------------------------------------------------------------------------------
-template <int FCH>  // Cout / 16
+template <typename HT> struct StemCvt;   // fp32 -> 16-bit MFMA operand element
+template <> struct StemCvt<bf16_t> { typedef bf16x8 vec; static __device__ __forceinline__ __bf16 cv(float v) { return (__bf16)v; } };
+template <> struct StemCvt<f16_t> { typedef f16x8 vec; static __device__ __forceinline__ _Float16 cv(float v) { return (_Float16)v; } };
+template <typename HT> __device__ __forceinline__ uint32_t pk16(float a, float b);
+template <> __device__ __forceinline__ uint32_t pk16<bf16_t>(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pk16<f16_t>(float a, float b) { return pk_h2(a, b); }
+
+template <int FCH, typename HT>  // Cout / 16; bf16_t or f16_t output
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                        const float* __restrict__ lnb, float eps, bf16_t* __restrict__ y,
-                                                        bf16_t* __restrict__ raw, int N, int H, int W) {
+                                                        const float* __restrict__ lnb, float eps, HT* __restrict__ y,
+                                                        HT* __restrict__ raw, int N, int H, int W) {
+  typedef typename StemCvt<HT>::vec hvec;
   constexpr int Cout = FCH * 16;
   const int lane = threadIdx.x & 63, nq = lane & 15, q = lane >> 4;
   const int Ho = H >> 2, Wo = W >> 2;
   const long groups = (long)N * Ho * (Wo >> 4);
   // weight fragments: A[m = ch][k], k = 32 ks + 8 q + j, zero for k >= 48
-  bf16x8 afr[FCH][2];
+  hvec afr[FCH][2];
 #pragma unroll
   for (int f = 0; f < FCH; ++f)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int k0 = ks * 32 + q * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) afr[f][ks][j] = (k0 + j < 48) ? (__bf16)w[(f * 16 + nq) * 48 + k0 + j] : (__bf16)0.f;
+      for (int j = 0; j < 8; ++j) afr[f][ks][j] = StemCvt<HT>::cv((k0 + j < 48) ? w[(f * 16 + nq) * 48 + k0 + j] : 0.f);
     }
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   for (long g = wave_id; g < groups; g += nwaves) {
@@ -101,18 +109,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const long ny = g / (Wo >> 4);
     const int oy = (int)(ny % Ho), n = (int)(ny / Ho);
     const int ox = xg * 16 + nq;
-    bf16x8 bfr[2];
+    hvec bfr[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kc = ks * 4 + q;  // 8-wide k chunk: channel kc/2, kernel rows 2*(kc&1), +1
       if (kc < 6) {
         const float* src = x + (((long)n * 3 + (kc >> 1)) * H + (oy * 4 + (kc & 1) * 2)) * W + ox * 4;
         const float4 r0 = *reinterpret_cast<const float4*>(src), r1 = *reinterpret_cast<const float4*>(src + W);
-        bfr[ks][0] = (__bf16)r0.x; bfr[ks][1] = (__bf16)r0.y; bfr[ks][2] = (__bf16)r0.z; bfr[ks][3] = (__bf16)r0.w;
-        bfr[ks][4] = (__bf16)r1.x; bfr[ks][5] = (__bf16)r1.y; bfr[ks][6] = (__bf16)r1.z; bfr[ks][7] = (__bf16)r1.w;
+        bfr[ks][0] = StemCvt<HT>::cv(r0.x); bfr[ks][1] = StemCvt<HT>::cv(r0.y); bfr[ks][2] = StemCvt<HT>::cv(r0.z); bfr[ks][3] = StemCvt<HT>::cv(r0.w);
+        bfr[ks][4] = StemCvt<HT>::cv(r1.x); bfr[ks][5] = StemCvt<HT>::cv(r1.y); bfr[ks][6] = StemCvt<HT>::cv(r1.z); bfr[ks][7] = StemCvt<HT>::cv(r1.w);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bfr[ks][j] = (__bf16)0.f;
+        for (int j = 0; j < 8; ++j) bfr[ks][j] = StemCvt<HT>::cv(0.f);
       }
     }
     f32x4 acc[FCH];
@@ -120,8 +128,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
     for (int f = 0; f < FCH; ++f) {
       acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[f][0], bfr[0], acc[f], 0, 0, 0);
-      acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[f][1], bfr[1], acc[f], 0, 0, 0);
+      acc[f] = mfma_16x16x32<HT>(__builtin_bit_cast(uint4, afr[f][0]), __builtin_bit_cast(uint4, bfr[0]), acc[f]);
+      acc[f] = mfma_16x16x32<HT>(__builtin_bit_cast(uint4, afr[f][1]), __builtin_bit_cast(uint4, bfr[1]), acc[f]);
       const float4 bv = *reinterpret_cast<const float4*>(bias + f * 16 + q * 4);
       acc[f][0] += bv.x; acc[f][1] += bv.y; acc[f][2] += bv.z; acc[f][3] += bv.w;
       s += (acc[f][0] + acc[f][1]) + (acc[f][2] + acc[f][3]);
@@ -138,22 +146,22 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     v += __shfl_xor(v, 32, 64);
     const float rstd = rsqrtf(v * (1.0f / Cout) + eps);
     if (raw) {   // training: the LayerNorm input
-      bf16_t* ro = raw + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
+      HT* ro = raw + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
 #pragma unroll
       for (int f = 0; f < FCH; ++f) {
         uint2 o;
-        o.x = (uint32_t)f2bf(acc[f][0]) | ((uint32_t)f2bf(acc[f][1]) << 16);
-        o.y = (uint32_t)f2bf(acc[f][2]) | ((uint32_t)f2bf(acc[f][3]) << 16);
+        o.x = pk16<HT>(acc[f][0], acc[f][1]);
+        o.y = pk16<HT>(acc[f][2], acc[f][3]);
         *reinterpret_cast<uint2*>(ro + f * 16) = o;
       }
     }
-    bf16_t* yo = y + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
+    HT* yo = y + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
 #pragma unroll
     for (int f = 0; f < FCH; ++f) {
       const float4 gw = *reinterpret_cast<const float4*>(lnw + f * 16 + q * 4), gb = *reinterpret_cast<const float4*>(lnb + f * 16 + q * 4);
       uint2 o;
-      o.x = (uint32_t)f2bf((acc[f][0] - mean) * rstd * gw.x + gb.x) | ((uint32_t)f2bf((acc[f][1] - mean) * rstd * gw.y + gb.y) << 16);
-      o.y = (uint32_t)f2bf((acc[f][2] - mean) * rstd * gw.z + gb.z) | ((uint32_t)f2bf((acc[f][3] - mean) * rstd * gw.w + gb.w) << 16);
+      o.x = pk16<HT>((acc[f][0] - mean) * rstd * gw.x + gb.x, (acc[f][1] - mean) * rstd * gw.y + gb.y);
+      o.y = pk16<HT>((acc[f][2] - mean) * rstd * gw.z + gb.z, (acc[f][3] - mean) * rstd * gw.w + gb.w);
       *reinterpret_cast<uint2*>(yo + f * 16) = o;
     }
   }
@@ -424,11 +432,14 @@ static int stem_entry(const float* x, const float* w, const float* bias, const f
   const unsigned blocks = (unsigned)((total + PIX - 1) / PIX > 4096 ? 4096 : (total + PIX - 1) / PIX);
   const size_t lds = (size_t)PIX * (48 + Cout) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (out_dtype == MTBT_BF16 && Cout == 96 && (W / 4) % 16 == 0 && bias && aligned16(w) && aligned16(bias) && aligned16(ln_w) &&
+  if ((out_dtype == MTBT_BF16 || out_dtype == MTBT_F16) && Cout == 96 && (W / 4) % 16 == 0 && bias && aligned16(w) && aligned16(bias) && aligned16(ln_w) &&
       aligned16(ln_b) && aligned16(y) && aligned16(raw)) {
     const long groups = (long)N * (H / 4) * (W / 64);
     const unsigned nb = (unsigned)((groups + 3) / 4 > 2048 ? 2048 : (groups + 3) / 4);
-    hipLaunchKernelGGL((stem_mfma_kernel<6>), dim3(nb), dim3(256), 0, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, (bf16_t*)raw, N, H, W);
+    if (out_dtype == MTBT_BF16)
+      hipLaunchKernelGGL((stem_mfma_kernel<6, bf16_t>), dim3(nb), dim3(256), 0, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, (bf16_t*)raw, N, H, W);
+    else
+      hipLaunchKernelGGL((stem_mfma_kernel<6, f16_t>), dim3(nb), dim3(256), 0, s, x, w, bias, ln_w, ln_b, ln_eps, (f16_t*)y, (f16_t*)raw, N, H, W);
     MTBT_LAUNCH_CHECK();
     return MTBT_OK;
   }
@@ -436,6 +447,8 @@ static int stem_entry(const float* x, const float* w, const float* bias, const f
     hipLaunchKernelGGL((stem_kernel<float, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (float*)y, (float*)raw, N, H, W, Cout, G);
   else if (out_dtype == MTBT_BF16)
     hipLaunchKernelGGL((stem_kernel<bf16_t, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (bf16_t*)y, (bf16_t*)raw, N, H, W, Cout, G);
+  else if (out_dtype == MTBT_F16)
+    hipLaunchKernelGGL((stem_kernel<f16_t, PIX>), dim3(blocks), dim3(threads), lds, s, x, w, bias, ln_w, ln_b, ln_eps, (f16_t*)y, (f16_t*)raw, N, H, W, Cout, G);
   else return MTBT_EINVAL;
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
@@ -469,6 +482,7 @@ extern "C" int mtbt_layernorm_nhwc(const void* x, const float* w, const float* b
        else if (CH8 <= 128) LN_LAUNCH(T, 2, 64); else LN_LAUNCH(T, 4, 64); } while (0)
   if (dtype == MTBT_F32) LN_BY_C(float);
   else if (dtype == MTBT_BF16) LN_BY_C(bf16_t);
+  else if (dtype == MTBT_F16) LN_BY_C(f16_t);
   else return MTBT_EINVAL;
 #undef LN_BY_C
 #undef LN_LAUNCH
@@ -520,6 +534,7 @@ extern "C" int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == MTBT_F32) hipLaunchKernelGGL((fuse_kernel<float>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);
   else if (a->dtype == MTBT_BF16) hipLaunchKernelGGL((fuse_kernel<bf16_t>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);
+  else if (a->dtype == MTBT_F16) hipLaunchKernelGGL((fuse_kernel<f16_t>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);
   else return MTBT_EINVAL;
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
@@ -540,6 +555,7 @@ extern "C" int mtbt_gap_fc(const void* x, const float* w, const float* b, float*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == MTBT_F32) hipLaunchKernelGGL((gap_fc_kernel<float>), dim3(N), dim3(threads), lds, s, (const float*)x, w, b, y, HW, C, nout);
   else if (dtype == MTBT_BF16) hipLaunchKernelGGL((gap_fc_kernel<bf16_t>), dim3(N), dim3(threads), lds, s, (const bf16_t*)x, w, b, y, HW, C, nout);
+  else if (dtype == MTBT_F16) hipLaunchKernelGGL((gap_fc_kernel<f16_t>), dim3(N), dim3(threads), lds, s, (const f16_t*)x, w, b, y, HW, C, nout);
   else return MTBT_EINVAL;
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
@@ -553,6 +569,8 @@ extern "C" int mtbt_cast(const void* src, void* dst, int64_t n, int sd, int dd, 
   else if (sd == MTBT_BF16 && dd == MTBT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, (long)n);
   else if (sd == MTBT_F32 && dd == MTBT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, (long)n);
   else if (sd == MTBT_BF16 && dd == MTBT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+  else if (sd == MTBT_F32 && dd == MTBT_F16) hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (f16_t*)dst, (long)n);
+  else if (sd == MTBT_F16 && dd == MTBT_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(g), dim3(256), 0, s, (const f16_t*)src, (float*)dst, (long)n);
   else return MTBT_EINVAL;
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;

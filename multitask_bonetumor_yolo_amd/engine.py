@@ -13,8 +13,8 @@ import torch
 
 from . import _lib as L
 
-TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16}
-ESIZE = {L.F32: 4, L.BF16: 2}
+TORCH_DTYPE = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16}
+ESIZE = {L.F32: 4, L.BF16: 2, L.F16: 2}
 
 
 def code_of(dtype: torch.dtype) -> int:
@@ -22,7 +22,9 @@ def code_of(dtype: torch.dtype) -> int:
         return L.F32
     if dtype == torch.bfloat16:
         return L.BF16
-    raise ValueError(f"unsupported compute dtype {dtype}: float32 (parity) or bfloat16 (throughput)")
+    if dtype == torch.float16:
+        return L.F16
+    raise ValueError(f"unsupported compute dtype {dtype}: float32 (parity), bfloat16 (throughput) or float16 (inference, BASELINE configs[4])")
 
 
 @dataclass
@@ -455,11 +457,11 @@ class Plan:
         self._io([x], [y])
 
     def mlp_fused(self, t: Act, res: Act, w1, b1, w2p, b2, y: Act, name="mlp"):
-        """ConvNeXt fc1 + GELU + fc2 (+ residual) in one launch (mlp_fused.hip); bf16, d in {96, 192}."""
-        assert t.dense and res.dense and y.dense and t.code == L.BF16 and t.C in (96, 192)
+        """ConvNeXt fc1 + GELU + fc2 (+ residual) in one launch (mlp_fused.hip); bf16 / fp16, d in {96, 192}."""
+        assert t.dense and res.dense and y.dense and t.code in (L.BF16, L.F16) and t.C in (96, 192)
         M, D = t.N * t.H * t.W, t.C
-        args = (t.ptr, res.ptr, w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), y.ptr, M, D)
-        self.launches.append(Launch(self.lib.mtbt_convnext_mlp_fused, args, name, (t.buf, res.buf, w1, b1, w2p, b2, y.buf),
+        args = (t.ptr, res.ptr, w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), y.ptr, M, D, t.code)
+        self.launches.append(Launch(self.lib.mtbt_convnext_mlp_fused_dt, args, name, (t.buf, res.buf, w1, b1, w2p, b2, y.buf),
                                     2.0 * M * D * 4 * D * 2, 3.0 * M * D * 2 + 2.0 * 4 * D * D * 2))
         self._io([t, res], [y])
 

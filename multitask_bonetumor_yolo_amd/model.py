@@ -373,7 +373,7 @@ class _Lowering:
             sb = self.subbatch(si, a)
             out_full = self.p.new(a.N, a.H, a.W, d, self.code)
             t = self.p.new(sb, a.H, a.W, d, self.code)
-            fused = self.code == L.BF16 and d in (96, 192) and sb == a.N and os.environ.get("MTBT_FUSED_MLP", "1") == "1"
+            fused = self.code in (L.BF16, L.F16) and d in (96, 192) and sb == a.N and os.environ.get("MTBT_FUSED_MLP", "1") == "1"
             h = None if fused else self.p.new(sb, a.H, a.W, 4 * d, self.code)
             pp_ = [self.p.new(sb, a.H, a.W, d, self.code) for _ in range(2)] if len(st.blocks) > 1 else []
             consts = []
@@ -384,7 +384,7 @@ class _Lowering:
                                self.W(blk.mlp.fc2.weight.detach().float() * g[:, None]), self.F(g * blk.mlp.fc2.bias.detach().float())))
             w2p = [self.p.const(_permute_hidden(c_[6]), self.dt) for c_ in consts] if fused else None
             # bf16 mode: polynomial GELU (|err| <= 2.3e-4, below bf16 resolution); fp32 parity mode: the erf form
-            gelu = L.ACT_GELU_POLY if self.code == L.BF16 and os.environ.get("MTBT_GELU_POLY", "1") == "1" else L.ACT_GELU
+            gelu = L.ACT_GELU_POLY if self.code in (L.BF16, L.F16) and os.environ.get("MTBT_GELU_POLY", "1") == "1" else L.ACT_GELU
             for n0 in range(0, a.N, sb):
                 nn_ = min(sb, a.N - n0)
                 view = lambda act, k=nn_, o=n0: Act(act.buf, act.off + o * act.bs, k, act.H, act.W, act.C, act.ld, act.bs)

@@ -956,6 +956,8 @@ def train_forward(model, x: torch.Tensor):
         raise RuntimeError("ConvNeXtBiFPNYOLO (HIP) needs CUDA/HIP tensors on an MI355X; there is no CPU path")
     if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
         raise ValueError(f"expected [B,3,S,S] with S a multiple of 32, got {tuple(x.shape)}")
+    if model.compute_dtype == torch.float16:
+        raise NotImplementedError("float16 is an inference arithmetic mode (BASELINE configs[4]); train in bfloat16 or float32")
     cache = model.__dict__.setdefault("_train_plans", {})
     key = (tuple(x.shape), model.compute_dtype, x.device.index, _bn_mode_sig(model))
     tp = cache.get(key)

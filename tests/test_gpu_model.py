@@ -388,3 +388,122 @@ def test_graph_outlives_plan_eviction_and_refuses_stale_weights():
     hip.mark_weights_updated()                        # what raw-pointer updates (fused optimiser) must call
     with pytest.raises(RuntimeError, match="changed since the capture"):
         g2.replay()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Parity where the benchmark actually runs: 640 x 640 (configs[1]) and 1280 x 1280 (configs[4]).  At these sizes the 80^2 / 160^2 maps
+# take kernel instances the small cases above never reach end to end (direct 3x3 with multi-tile halos, fused MLP over 409 600
+# pixels, the 4-lane schedule).  The oracle forward costs ~0.4 s (640) / ~1.6 s (1280) per image on the box's host cores.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _out_list(out):
+    seg_feats, mc, protos = out["segment_protos"]
+    return {"det0": out["detect_features"][0], "det1": out["detect_features"][1], "det2": out["detect_features"][2],
+            "seg0": seg_feats[0], "seg2": seg_feats[2], "mc": mc, "protos": protos, "logits": out["img_cls_logits"]}
+
+
+def _kept_agreement(a_boxes, a_cnt, b_boxes, b_cnt, tol):
+    """fraction of a's kept boxes that have a box of b within `tol` pixels (all four coordinates)"""
+    hit = tot = 0
+    for n in range(a_boxes.shape[0]):
+        A, Bx = a_boxes[n, :int(a_cnt[n])].cpu(), b_boxes[n, :int(b_cnt[n])].cpu()
+        tot += len(A)
+        if len(A) and len(Bx):
+            hit += int(((A[:, None, :] - Bx[None, :, :]).abs().amax(dim=2).amin(dim=1) <= tol).sum())
+    return hit / max(tot, 1)
+
+
+def test_infer_fp32_parity_at_640(pair):
+    ora, hip = pair
+    hip.set_compute_dtype(torch.float32)
+    x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(640))
+    with torch.no_grad():
+        ref, out = _out_list(ora(x, "infer")), _out_list(hip(x.to(DEV), "infer"))
+    torch.cuda.synchronize()
+    for k in ref:
+        assert out[k].shape == ref[k].shape and maxdiff(out[k], ref[k]) < 1e-3, (k, maxdiff(out[k], ref[k]))
+
+
+def test_infer_bf16_at_640_per_output_bounds(pair):
+    """bf16 (the benchmarked mode) at the benchmarked size, per output: absolute error against the oracle bounded relative to that output's
+    own scale; and what the post-process consumes agrees with the fp32 HIP path anchor by anchor: decoded boxes within 2 px for >= 99 % of
+    the 2 x 8400 anchors, best class scores within 0.03 everywhere.  (With random-init weights ~all anchors score ~0.5, so the SET of 100
+    boxes NMS keeps is decided by differences far below any arithmetic's resolution -- it is compared bit for bit on identical inputs in
+    test_postprocess_pipeline_on_model_outputs, not across precisions.)"""
+    ora, hip = pair
+    S = 640
+    x = torch.rand(2, 3, S, S, generator=torch.Generator().manual_seed(641))
+    with torch.no_grad():
+        ref = _out_list(ora(x, "infer"))
+        hip.set_compute_dtype(torch.float32)
+        d32 = pp.decode_boxes(hip(x.to(DEV), "infer")["detect_features"], S)
+        hip.set_compute_dtype(torch.bfloat16)
+        b16 = hip(x.to(DEV), "infer")
+        d16 = pp.decode_boxes(b16["detect_features"], S)
+    torch.cuda.synchronize()
+    hip.set_compute_dtype(torch.float32)
+    out = _out_list(b16)
+    # bf16 keeps 8 mantissa bits; through ~100 layers the error stays a few percent of each output's dynamic range
+    for k, r in ref.items():
+        scale = r.abs().max().item()
+        assert maxdiff(out[k], r) <= 0.06 * scale + 1e-3, (k, maxdiff(out[k], r), scale)
+        assert relerr(out[k], r) < 3e-2, (k, relerr(out[k], r))
+    box_err = (d16["boxes"] - d32["boxes"]).abs().amax(dim=2)
+    assert (box_err <= 2.0).float().mean().item() >= 0.99, (box_err <= 2.0).float().mean().item()
+    assert (d16["best_score"] - d32["best_score"]).abs().max().item() <= 0.03
+
+
+def test_infer_fp16_at_1280_vs_oracle(pair):
+    """BASELINE configs[4]'s arithmetic and shape: fp16 storage, v_mfma_f32_16x16x32_f16, 1280 x 1280.  fp16 keeps 11 mantissa bits (8x
+    bf16's resolution) inside +-65504: outputs within 1 % of each output's range / 5e-3 relative L2 of the fp32 oracle; the NMS kept
+    indices equal the oracle NMS run on the SAME (GPU-decoded) boxes bit for bit."""
+    ora, hip = pair
+    S = 1280
+    x = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(1280))
+    with torch.no_grad():
+        ref = _out_list(ora(x, "infer"))
+        hip.set_compute_dtype(torch.float16)
+        raw = hip(x.to(DEV), "infer")
+    out = _out_list(raw)
+    torch.cuda.synchronize()
+    hip.set_compute_dtype(torch.float32)
+    for k, r in ref.items():
+        assert torch.isfinite(out[k]).all(), k
+        scale = r.abs().max().item()
+        assert maxdiff(out[k], r) <= 1e-2 * scale + 1e-3, (k, maxdiff(out[k], r), scale)
+        assert relerr(out[k], r) < 5e-3, (k, relerr(out[k], r))
+    res = pp.detect_and_segment(raw["detect_features"], raw["segment_protos"][1], raw["segment_protos"][2], S)
+    d = pp.decode_boxes(raw["detect_features"], S)
+    torch.cuda.synchronize()
+    k, *_ = opp.filter_and_nms(d["boxes"][0].cpu(), d["scores"][0].cpu(), S)
+    n = int(res["counts"][0])
+    assert n == len(k) and torch.equal(res["keep_idx"][0, :n].cpu(), k)
+
+
+def test_infer_fp16_batch64_1280_properties():
+    """configs[4] at full size (batch 64, 1280 x 1280, fp16) through size-independent properties: every output finite, every image's result
+    identical to the same image run in a batch of 4 (images are independent: no cross-image arithmetic, tile order does not change a
+    pixel's reduction order), kept boxes sorted by score, inside the image, at most top-k."""
+    from multitask_bonetumor_yolo_amd import init_synthetic_
+    torch.manual_seed(64)
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.float16)
+    S, B = 1280, 64
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(65)).to(DEV)
+    fwd, det = hip.infer_and_detect(x, S, masks=False)
+    big = {k: v.clone() for k, v in _out_list(fwd).items()}
+    kept = {k: det[k].clone() for k in ("keep_idx", "counts", "boxes", "scores")}
+    torch.cuda.synchronize()
+    for k, v in big.items():
+        assert torch.isfinite(v).all(), k
+    for lo in (0, 60):
+        fs, ds = hip.infer_and_detect(x[lo:lo + 4].contiguous(), S, masks=False)
+        small = _out_list(fs)
+        torch.cuda.synchronize()
+        for k, v in small.items():
+            assert torch.equal(v, big[k][lo:lo + 4]), (k, lo)
+        assert torch.equal(ds["keep_idx"], kept["keep_idx"][lo:lo + 4]) and torch.equal(ds["counts"], kept["counts"][lo:lo + 4])
+    cnt = kept["counts"].cpu()
+    assert int(cnt.max()) <= 100 and int(cnt.sum()) > 0
+    for n in range(B):
+        c = int(cnt[n])
+        sc, bx = kept["scores"][n, :c].cpu(), kept["boxes"][n, :c].cpu()
+        assert torch.all(sc[:-1] >= sc[1:]) and bx.min().item() >= 0 and bx.max().item() <= S
