@@ -60,70 +60,88 @@ __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__
   });
 }
 
-// Depthwise weight gradient: dW[tap][c] = sum_p dy[p][c] * x[p shifted by the tap][c] (zero outside the image).  grid.y = filter ROW:
-// a thread keeps the KS taps of that row for its 8 channels, so dy is read once and x KS times per row (8 instead of 14 tensor reads
-// per row of a 7x7 filter).  Row groups as in rows_reduce; partial: [workgroup][k*k*C].  A halo-tile version that forms all taps from
-// one staged tile is the follow-up.
+// ------------------------------------------------------------------------------------------------------------------------------
+// Depthwise weight gradient from an LDS-resident halo tile (the forward kernel's data flow, reduction instead of convolution):
+//   dW[ky][kx][c] = sum over pixels (y, x) of dy[y][x][c] * X[y + ky - P][x + kx - P][c]
+// Workgroup = 4 waves, one 128-channel chunk (lane = channel pair), PERSISTENT over 8 x 8-pixel tiles; wave w owns tile rows 2w, 2w+1.
+// Per tile the (8+KS-1)^2 input halo and the 64 dy pixels of the chunk are staged in LDS (16-byte loads); a halo row segment of
+// 8 + KS - 1 pairs is read once and feeds all KS horizontal taps of 8 output pixels (KS * 8 packed FMAs per KS + 7 LDS reads).
+// The KS*KS tap accumulators (fp32 pairs) stay in registers across tiles; one partial row per WAVE is written at the end and the
+// shared second level (channel_sum_final) adds the rows in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef float f32p __attribute__((ext_vector_type(2)));
+
+template <typename T> __device__ __forceinline__ f32p ld_pair(const char* p);
+template <> __device__ __forceinline__ f32p ld_pair<float>(const char* p) { return *reinterpret_cast<const f32p*>(p); }
+template <> __device__ __forceinline__ f32p ld_pair<bf16_t>(const char* p) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  return f32p{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void dw_wgrad_partial(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
-                                                        float* __restrict__ partial) {
-  __shared__ float red[256 * 8];
-  const int tid = threadIdx.x, chunks = C >> 3, fr = blockIdx.y, r = fr - KS / 2;
-  const bool par = chunks < 256;
-  const int rpp = par ? 256 / chunks : 1, rg = par ? tid / chunks : 0, ch0 = par ? tid - rg * chunks : tid;
-  const long P = (long)N * H * W;
-  const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK, p1 = min(P, p0 + ROWS_PER_BLOCK);
-  float* dst = partial + (long)blockIdx.x * KS * KS * C + (long)fr * KS * C;
-  for (int ch = ch0; ch < chunks; ch += (par ? chunks : 256)) {     // row-group mode: exactly one trip for every thread
-    float s[KS][8];
+__global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
+                                                            float* __restrict__ partial /* [slots * 4][KS*KS*C] */) {
+  constexpr int PAD = KS / 2, TS = 8, IW = TS + KS - 1, ES = (int)sizeof(T), PIXB = 128 * ES, EPC = 16 / ES, PARTS = PIXB / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xt = smem;                       // [IW*IW][128] T
+  char* dt = smem + IW * IW * PIXB;      // [64][128] T
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunks = (C + 127) / 128;
+  const int chunk = blockIdx.x % chunks, slot = blockIdx.x / chunks, nslots = gridDim.x / chunks;
+  const int cb = chunk * 128, cc = min(128, C - cb);
+  const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+  const long ntiles = (long)N * tiles_y * tiles_x;
+  const bool active = lane * 2 < cc;
+  f32p acc[KS * KS];
 #pragma unroll
-    for (int t = 0; t < KS; ++t)
+  for (int t = 0; t < KS * KS; ++t) acc[t] = f32p{0.f, 0.f};
+  for (long tl = slot; tl < ntiles; tl += nslots) {
+    const int tx = (int)(tl % tiles_x), ty = (int)((tl / tiles_x) % tiles_y), n = (int)(tl / ((long)tiles_x * tiles_y));
+    const int y0 = ty * TS, x0 = tx * TS;
+    __syncthreads();                                       // the previous tile's readers are done
+    for (int it = tid; it < IW * IW * PARTS; it += 256) {   // halo: zeros outside the image / past the chunk's channels
+      const int pix = it / PARTS, part = it - pix * PARTS;
+      const int r = pix / IW, c = pix - r * IW;
+      const int iy = y0 + r - PAD, ix = x0 + c - PAD;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && part * EPC < cc)
+        v = *reinterpret_cast<const uint4*>(x + (((long)n * H + iy) * W + ix) * C + cb + part * EPC);
+      *reinterpret_cast<uint4*>(xt + pix * PIXB + part * 16) = v;
+    }
+    for (int it = tid; it < TS * TS * PARTS; it += 256) {
+      const int pix = it / PARTS, part = it - pix * PARTS;
+      const int oy = y0 + pix / TS, ox = x0 + pix % TS;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (oy < H && ox < W && part * EPC < cc) v = *reinterpret_cast<const uint4*>(dy + (((long)n * H + oy) * W + ox) * C + cb + part * EPC);
+      *reinterpret_cast<uint4*>(dt + pix * PIXB + part * 16) = v;
+    }
+    __syncthreads();
+    if (active) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s[t][k] = 0.f;
-    if (rg < rpp) {
-      for (long p = p0 + rg; p < p1; p += rpp) {
-        const int n = (int)(p / ((long)H * W)), rem = (int)(p - (long)n * H * W);
-        const int y = rem / W + r, xx = rem % W;
-        if ((unsigned)y >= (unsigned)H) continue;
-        float a[8];
-        ld8(dy + p * C + ch * 8, a);
-        const T* xr = x + (((long)n * H + y) * W) * C + ch * 8;
+      for (int a = 0; a < 2; ++a) {
+        const int row = 2 * wave + a;
+        f32p g[TS];
 #pragma unroll
-        for (int t = 0; t < KS; ++t) {
-          const int ix = xx + t - KS / 2;
-          if ((unsigned)ix < (unsigned)W) {
-            float b[8];
-            ld8(xr + (long)ix * C, b);
+        for (int i = 0; i < TS; ++i) g[i] = ld_pair<T>(dt + (row * TS + i) * PIXB + lane * 2 * ES);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s[t][k] += a[k] * b[k];
-          }
+        for (int ky = 0; ky < KS; ++ky) {
+          f32p in[IW];
+#pragma unroll
+          for (int j = 0; j < IW; ++j) in[j] = ld_pair<T>(xt + ((row + ky) * IW + j) * PIXB + lane * 2 * ES);
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int i = 0; i < TS; ++i) acc[ky * KS + kx] = __builtin_elementwise_fma(g[i], in[i + kx], acc[ky * KS + kx]);
         }
       }
     }
-    if (!par) {
+  }
+  // partial row (slot, wave): the workgroups of one slot (one per chunk) write disjoint column ranges of the same rows, so every row
+  // is complete without any zero fill
+  float* dst = partial + ((long)slot * 4 + wave) * KS * KS * C;
+  if (active) {
 #pragma unroll
-      for (int t = 0; t < KS; ++t)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dst[(long)t * C + ch * 8 + k] = s[t][k];
-    } else {
-#pragma unroll
-      for (int t = 0; t < KS; ++t) {
-        if (rg < rpp) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) red[(rg * chunks + ch) * 8 + k] = s[t][k];
-        }
-        __syncthreads();
-        if (rg == 0) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            float v = 0.f;
-            for (int g = 0; g < rpp; ++g) v += red[(g * chunks + ch) * 8 + k];
-            dst[(long)t * C + ch * 8 + k] = v;
-          }
-        }
-        __syncthreads();
-      }
-    }
+    for (int t = 0; t < KS * KS; ++t) *reinterpret_cast<f32p*>(dst + (long)t * C + cb + lane * 2) = acc[t];
   }
 }
 
@@ -193,28 +211,43 @@ extern "C" int mtbt_channel_affine2(const void* x1, const void* x2, const float*
   return MTBT_OK;
 }
 
+static int dw_wgrad_blocks(int N, int H, int W, int C) {
+  const int chunks = (C + 127) / 128;
+  const long tiles = (long)N * ((H + 7) / 8) * ((W + 7) / 8);
+  long slots = 512 / chunks;                        // ~2 workgroups per CU over all chunks
+  if (slots < 1) slots = 1;
+  if (slots > tiles) slots = tiles;
+  return (int)(slots * chunks);
+}
+
 extern "C" int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0) return 0;
-  return (((int64_t)N * H * W + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * (int64_t)ksize * ksize * C * (int64_t)sizeof(float);
+  return (int64_t)(dw_wgrad_blocks(N, H, W, C) / ((C + 127) / 128)) * 4 * ksize * ksize * C * (int64_t)sizeof(float);
 }
 
 extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
                                  void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (ksize != 3 && ksize != 7)) return MTBT_EINVAL;
+  if (dtype != MTBT_BF16 && dtype != MTBT_F32) return MTBT_EINVAL;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return MTBT_EALIGN;
   if (workspace_bytes < mtbt_dwconv_wgrad_workspace_bytes(N, H, W, C, ksize)) return MTBT_EWORKSPACE;
-  const long blocks = ((long)N * H * W + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  const int blocks = dw_wgrad_blocks(N, H, W, C);
+  const int chunks = (C + 127) / 128;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
-  const dim3 grid((unsigned)blocks, (unsigned)ksize);
-#define DWW(T, KSV) hipLaunchKernelGGL((dw_wgrad_partial<T, KSV>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, N, H, W, C, partial)
-  if (dtype == MTBT_BF16) { if (ksize == 7) DWW(bf16_t, 7); else DWW(bf16_t, 3); }
-  else if (dtype == MTBT_F32) { if (ksize == 7) DWW(float, 7); else DWW(float, 3); }
-  else return MTBT_EINVAL;
-#undef DWW
   const int n = ksize * ksize * C;
-  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, (int)blocks, n, dw, accumulate);
+  const int es = dtype == MTBT_F32 ? 4 : 2;
+  const int iw = 8 + ksize - 1;
+  const int lds = (iw * iw + 64) * 128 * es;
+#define DWT(T, KSV)                                                                                                      \
+  do {                                                                                                                  \
+    if (int rc = mtbt_allow_lds(dw_wgrad_tile_kernel<T, KSV>, lds)) return rc;                                           \
+    hipLaunchKernelGGL((dw_wgrad_tile_kernel<T, KSV>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)dy, (const T*)x, N, H, W, C, partial); \
+  } while (0)
+  if (dtype == MTBT_BF16) { if (ksize == 7) DWT(bf16_t, 7); else DWT(bf16_t, 3); }
+  else { if (ksize == 7) DWT(float, 7); else DWT(float, 3); }
+#undef DWT
+  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, (blocks / chunks) * 4, n, dw, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
