@@ -33,33 +33,39 @@ IMG = 640
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=14.0):
+    """The CPU oracle (a port of the reference forward + post-process) on this host's cores, batch 1 and batch 16, each a
+    bounded sample: warm-up + as many timed iterations as fit the budget (at most 10)."""
     from oracle import postprocess as opp
     from oracle.model import ConvNeXtBiFPNYOLO as OracleModel, randomize_
     torch.manual_seed(0)
     m = randomize_(OracleModel(2, 2, pretrained_backbone=False)).eval()
-    x = torch.rand(1, 3, IMG, IMG, generator=torch.Generator().manual_seed(0))
     cores = min(len(os.sched_getaffinity(0)), 32)  # the GPU box shares its host; stay within a sane slice
     torch.set_num_threads(cores)
 
-    def one():
-        with torch.no_grad():
-            out = m(x, "infer")
-            feats, mc, protos = out["segment_protos"]
-            boxes, scores, _ = opp.decode_levels(out["detect_features"], IMG)
-            k, anchors, *_ = opp.filter_and_nms(boxes[0], scores[0], IMG)
-            if len(k):
-                opp.assemble_masks(mc[0][:, anchors].t(), protos[0], (IMG, IMG))
+    def run(batch, warm, budget):
+        x = torch.rand(batch, 3, IMG, IMG, generator=torch.Generator().manual_seed(0))
 
-    one()
-    t0 = time.time()
-    n = 0
-    while n < 10 and (time.time() - t0 < seconds_budget or n < 2):
-        one()
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 forward + decode/NMS/masks, batch 1 x {n} iterations at {IMG}x{IMG}"}
+        def one():
+            with torch.no_grad():
+                out = m(x, "infer")
+                feats, mc, protos = out["segment_protos"]
+                boxes, scores, _ = opp.decode_levels(out["detect_features"], IMG)
+                for b in range(batch):
+                    k, anchors, *_ = opp.filter_and_nms(boxes[b], scores[b], IMG)
+                    if len(k):
+                        opp.assemble_masks(mc[b][:, anchors].t(), protos[b], (IMG, IMG))
+        for _ in range(warm):
+            one()
+        t0, n = time.time(), 0
+        while n < 10 and (time.time() - t0 < budget or n < 1):
+            one()
+            n += 1
+        return batch * n / (time.time() - t0), n
+    v1, n1 = run(1, 3, seconds_budget * 0.4)
+    v16, n16 = run(16, 1, seconds_budget * 0.6)
+    return {"value": round(v1, 3), "value_batch16": round(v16, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 forward + decode/NMS/masks at {IMG}x{IMG}: batch 1, 3 warm-ups + {n1} iterations; batch 16, 1 warm-up + {n16} iterations"}
 
 
 def synthetic_targets(B, S, seed, dev):
@@ -275,14 +281,27 @@ def main():
                   f"pool {c.plan.pool.bytes/2**20:.0f} MiB", file=sys.stderr)
         # HBM-side traffic of the same kernels: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command, summarised
         # by tools/summarize_pmc.py with the guide's gfx950 corrections; bench.py cannot run the profiler on itself
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_all = None, None, None
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
             if name.endswith("_traffic.json") and args.dtype == "bf16" and (B, IMG) == (BATCH_PER_GPU, 640):
                 with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic, traffic_src = round(json.load(f)["traffic_bytes_per_launch"]), "profiles/" + name
+                    tj = json.load(f)
+                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + name
+                traffic_all = {k: round(v["traffic_bytes_per_launch"]) for k, v in tj.get("families", {}).items()}
                 break
         conv_bytes = sum(l.bytes for l, _ in conv)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        # the north star's 0.70 target is stated on the 3x3 kernels alone: their own FLOPs over their own time
+        c33 = [(l, t) for l, t in conv if l.keep[0].R == 3 and l.keep[0].S == 3]
+        f33, t33 = sum(l.flops for l, _ in c33), sum(t for _, t in c33)
+        # HBM-class kernels (depthwise 7x7 + LayerNorm, depthwise 3x3, BiFPN fusion, LayerNorm2d, stem): algorithmic in + out bytes over their time
+        hbm_fns = {"mtbt_dwconv_nhwc": "dwconv", "mtbt_bifpn_fuse": "bifpn_fuse", "mtbt_layernorm_nhwc": "layernorm", "mtbt_stem_conv4x4_ln": "stem"}
+        hbm = {}
+        for l, t in zip(c.plan.launches, ms):
+            k = hbm_fns.get(getattr(l.fn, "__name__", ""))
+            if k:
+                e = hbm.setdefault(k, [0.0, 0.0, 0])
+                e[0] += l.bytes; e[1] += t; e[2] += 1
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "f16") else 157.3
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_direct_kernel + conv3x3_rr_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
@@ -290,6 +309,13 @@ def main():
                     "launches_per_step": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
                     "flop_per_launch": round(conv_flops / len(conv)), "conv_ms_per_step": round(conv_ms, 3),
                     "all_kernels_ms_per_step": round(all_ms, 3)}
+        peak_hbm = 8000.0
+        roofline_3x3 = {"bound": "mfma", "kernel": "conv3x3_direct_kernel + conv3x3_rr_kernel + conv_igemm_kernel on 3x3 shapes", "launches_per_step": len(c33),
+                        "achieved": round(f33 / (t33 * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f33 / (t33 * 1e-3) / 1e12 / peak, 4),
+                        "ms_per_step": round(t33, 3), "target_frac": 0.70}
+        roofline_hbm = {k: {"bound": "hbm", "launches_per_step": v[2], "achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "peak": peak_hbm, "unit": "GB/s",
+                            "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / peak_hbm, 4), "ms_per_step": round(v[1], 3),
+                            "algorithmic_bytes_per_launch": round(v[0] / v[2]), "traffic": (traffic_all or {}).get(k)} for k, v in hbm.items()}
         line = {
             "metric": "images/sec at 640x640 multitask fwd (det+seg+cls) + decode/NMS/masks",
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -299,7 +325,7 @@ def main():
                                    f"+ decode + per-image NMS(top-100) + mask assembly; random-init weights",
                        "batch_per_gpu": B, "img": IMG, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "kept_boxes_per_image": float(res["counts"].float().mean().item())},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_3x3": roofline_3x3, "roofline_hbm": roofline_hbm,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

@@ -78,8 +78,8 @@ constexpr int CC = 128;  // channels per chunk = 64 lanes x 2
 // MAXCH = ceil(C / 128) chunks held in registers.  Workgroups are PERSISTENT: each walks a strided list of tiles
 // (XCD-contiguous ranges, so neighbouring tiles' halos meet in one L2); with a single chunk (C <= 128) the taps stay
 // in registers across tiles.
-template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB>
-__global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
+template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB, int OCC = 2, bool REGT = (MAXCH == 1)>
+__global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, OCC) void dwconv_kernel(
     const T* __restrict__ x, const T* __restrict__ w /* [KS*KS][C] */, const float* __restrict__ bias,
     const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, const float* __restrict__ scale,
     const float* __restrict__ shift, int act, T* __restrict__ y, T* __restrict__ raw, const T* res, int N, int H, int W,
@@ -96,7 +96,9 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
   constexpr int TILEB = IH * IWP * PIXB;
   // LayerNorm scratch: its own region when C <= 128 (the next tile's DMA is already landing in `tile` during the
   // epilogue); with several chunks it reuses the tile (LDS would otherwise not fit two workgroups per CU)
-  constexpr int REDOFF = MAXCH == 1 ? TILEB : 0;
+  constexpr int NTI_ = (KS * KS + (64 / (PIXB / 16)) - 1) / (64 / (PIXB / 16));
+  // single chunk: the scratch sits behind the tile (and behind the taps when those live in LDS): the next tile's DMA lands during the epilogue
+  constexpr int REDOFF = MAXCH == 1 ? TILEB + (REGT ? 0 : NTI_ * 1024) : 0;
   // several chunks: the chunk's KS*KS taps ride along with the halo tile ([tap][CC] T right behind it, PXI taps per
   // DMA wave-instruction) -- read row by row from L2 instead, each filter row waited ~1 us for its taps
   constexpr int NTI = (KS * KS + PXI - 1) / PXI;
@@ -118,9 +120,9 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
   // Taps (fp32 pairs of this lane's channel pair).  One chunk (C <= 128): all KS*KS stay in registers across the tiles.
   // More chunks: registers are needed for the accumulators of every chunk, so the taps are fetched row by row (KS at a
   // time, straight from L2) inside the unrolled row loop -- only two filter rows are live at once.
-  constexpr bool REGTAPS = MAXCH == 1;  // all KS*KS taps in registers
+  constexpr bool REGTAPS = REGT;        // all KS*KS taps in registers (single-chunk default); else they ride with the halo DMA into LDS
   f32x2 wr[REGTAPS ? KS * KS : 1];
-  if (MAXCH == 1 && lane * 2 < C) {
+  if (REGT && lane * 2 < C) {
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t) wr[REGTAPS ? t : 0] = Pair<T>::ld(w + (unsigned)(t * C + lane * 2));
   }
@@ -149,7 +151,7 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
   // image use an empty descriptor and columns outside it an out-of-range offset: both land as zeros.  Per instruction
   // the vector unit only adds one scalar to the lane's constant piece offset and tests its column.  Every wave issues its
   // DPW pieces back to back; the caller waits once (s_waitcnt vmcnt(0) + barrier).
-  auto stage = [&](int tl_, int cb) {
+  auto stage = [&](int tl_, int cb, bool with_taps) {
     const int tx_ = tl_ % tiles_x, ty_ = (tl_ / tiles_x) % tiles_y, n_ = tl_ / (tiles_x * tiles_y);
     const char* xn = reinterpret_cast<const char*>(x + (long)n_ * H * W * C);
 #pragma unroll
@@ -166,7 +168,7 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
       const unsigned vo = (unsigned)(ix0 + lane / PARTS) < (unsigned)W ? vlane + (unsigned)((ix0 * C + cb) * ES) : 0x80000000u;
       if (!(dbg & 2)) lds_dma16(srd, vo, 0, __builtin_amdgcn_readfirstlane(lds0 + (row * IWP + seg * PXI) * PIXB));
     }
-    if (MAXCH > 1) {
+    if (!REGT && with_taps) {
       srd_t wsrd = make_srd(w);
       wsrd.z = __builtin_amdgcn_readfirstlane((unsigned)(KS * KS * C * ES));   // taps past the last read as zeros
 #pragma unroll
@@ -203,7 +205,7 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
         // lanes 48..63, the last 16-lane pass -- then picks up bytes of the NEXT chunk.  That is the failure the removed
         // two / three-chunk kernel showed next to MFMA kernels (LDS port contention widens the window); see DESIGN.md 4.
         lds_barrier();
-        stage(tl, cb);
+        stage(tl, cb, MAXCH > 1 || first);   // (single chunk: the taps never change, staged once)
       }
       wait_vm<0>();
       __syncthreads();
@@ -255,10 +257,10 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
     const int oy0 = ty0 + sy * YB, ox0 = tx0 + sx * XB;
     T* yt = y + (((long)n * H + oy0) * W + ox0) * C;     // wave-uniform base; per-lane offsets below stay 32-bit
     const unsigned rowel = (unsigned)(W * C);
-    if (dbg & 4) { if (acc[0][0][0].x == 123.f) st_elem<T>(y, 0.f); if (MAXCH == 1) { __syncthreads(); if (tl + step < t_end) stage(tl + step, 0); } continue; }
+    if (dbg & 4) { if (acc[0][0][0].x == 123.f) st_elem<T>(y, 0.f); if (MAXCH == 1) { __syncthreads(); if (tl + step < t_end) stage(tl + step, 0, false); } continue; }
     if (MAXCH == 1) {   // one chunk: request the next tile now, it lands while this tile's epilogue runs
       lds_barrier();    // every wave's reads of the staged tile have returned (see the restaging barrier in chunk())
-      if (tl + step < t_end) stage(tl + step, 0);
+      if (tl + step < t_end) stage(tl + step, 0, false);
     }
     if constexpr (LN) {
       // + bias, per-pixel statistics over all C channels (held by this wave), normalise, store
@@ -360,22 +362,23 @@ __global__ __launch_bounds__((TH / 2) * (TW / XB) * 64, 2) void dwconv_kernel(
   }
 }
 
-template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB = 8>
+template <typename T, int KS, bool LN, int TH, int TW, int MAXCH, int XB = 8, int OCC = 2, bool REGT = (MAXCH == 1)>
 int launch_dw(const void* x, const void* w, const float* bias, const float* lnw, const float* lnb, float eps,
               const float* scale, const float* shift, int act, void* y, void* raw, const void* res, int N, int H, int W, int C, hipStream_t s) {
   constexpr int NT = (TH / 2) * (TW / XB) * 64;
   constexpr int PARTS = CC * (int)sizeof(T) / 16, PXI = 64 / PARTS, IWP = ((TW + KS - 1 + PXI - 1) / PXI) * PXI;
   constexpr int lds_tile = (TH + KS - 1) * IWP * CC * (int)sizeof(T), lds_red = LN ? (NT / 64) * (16 * 64 + 16) * 4 : 0;
-  constexpr int lds_taps = MAXCH == 1 ? 0 : ((KS * KS + PXI - 1) / PXI) * 1024;
-  constexpr int lds = MAXCH == 1 ? lds_tile + lds_red : (lds_tile + lds_taps > lds_red ? lds_tile + lds_taps : lds_red);
+  constexpr int lds_taps = REGT ? 0 : ((KS * KS + PXI - 1) / PXI) * 1024;
+  constexpr int lds = MAXCH == 1 ? lds_tile + lds_taps + lds_red : (lds_tile + lds_taps > lds_red ? lds_tile + lds_taps : lds_red);
   static_assert(lds <= 160 * 1024, "LDS");
   const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   if (tiles > 0x7fffffffL) return MTBT_EINVAL;
   // persistent workgroups: as many as stay resident (LDS-limited, at most 4 per CU), a multiple of the 8 XCDs
-  const long resident = 256L * (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds);
+  constexpr int cap = OCC > 4 ? OCC : 4;
+  const long resident = 256L * (160 * 1024 / lds > cap ? cap : 160 * 1024 / lds);
   long blocks = tiles < resident ? tiles : resident;
   blocks = (blocks + 7) / 8 * 8;
-  auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH, XB>;
+  auto kern = dwconv_kernel<T, KS, LN, TH, TW, MAXCH, XB, OCC, REGT>;
   if (int rc = mtbt_allow_lds(kern, lds)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, (const T*)x, (const T*)w, bias, lnw, lnb, eps, scale, shift,
                      act, (T*)y, (T*)raw, (const T*)res, N, H, W, C, 0 /* ablation bits: development builds only */);

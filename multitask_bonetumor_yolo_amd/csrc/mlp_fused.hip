@@ -245,7 +245,7 @@ static int mlp_entry(const void* t, const void* res, const void* w1, const float
                      int dtype, void* stream) {
   if (!t || !w1 || !b1 || !w2p || !b2 || !y || M <= 0 || M > 0x7fffff00L) return MTBT_EINVAL;
   if (dtype != MTBT_BF16 && dtype != MTBT_F16) return MTBT_EINVAL;
-  if (D != 96 && D != 192) return MTBT_EINVAL;
+  if (D != 96 && D != 192 && D != 384) return MTBT_EINVAL;
   if (!aligned16(t) || !aligned16(w1) || !aligned16(w2p) || !aligned16(y) || !aligned16(b1) || (res && !aligned16(res))) return MTBT_EALIGN;
   if ((long)4 * D * D * 2 >= 0x7fff0000L) return MTBT_EINVAL;
   MlpP p;
@@ -262,8 +262,11 @@ static int mlp_entry(const void* t, const void* res, const void* w1, const float
   // pixels per wave / waves per SIMD, measured (tools/mlp_probe.py): d = 96: 2 x 16 pixels at 4 waves per SIMD 100 us,
   // 3 x 16 at 3: 116, 4 x 16 at 2: 139 -- the kernel's skeleton (input / residual loads, stores) is latency-bound, so
   // residency beats the larger register tile; d = 192: 2 x 16 at 2: 110 us, 1 x 16 at 4: 125 (LDS-read bound).
-  if (dtype == MTBT_F16) return D == 96 ? launch_mlp<96, 2, 4, f16_t>(p, s) : launch_mlp<192, 2, 2, f16_t>(p, s);
-  return D == 96 ? launch_mlp<96, 2, 4, bf16_t>(p, s) : launch_mlp<192, 2, 2, bf16_t>(p, s);
+  // d = 384 (stage 2): three 48 KiB weight stages fill the LDS, so ONE workgroup per CU (one wave per SIMD, up to 512 registers): the
+  // wave keeps 2 x 16 pixels' inputs (96 registers) and their 384-channel outputs (192) in registers; per hidden chunk it reads 48
+  // weight fragments for 96 MFMAs -- LDS port 50 % busy, the fill path 32 B/clk.
+  if (dtype == MTBT_F16) return D == 96 ? launch_mlp<96, 2, 4, f16_t>(p, s) : (D == 192 ? launch_mlp<192, 2, 2, f16_t>(p, s) : launch_mlp<384, 2, 1, f16_t>(p, s));
+  return D == 96 ? launch_mlp<96, 2, 4, bf16_t>(p, s) : (D == 192 ? launch_mlp<192, 2, 2, bf16_t>(p, s) : launch_mlp<384, 2, 1, bf16_t>(p, s));
 }
 
 extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,

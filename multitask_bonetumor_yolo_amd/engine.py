@@ -458,7 +458,7 @@ class Plan:
 
     def mlp_fused(self, t: Act, res: Act, w1, b1, w2p, b2, y: Act, name="mlp"):
         """ConvNeXt fc1 + GELU + fc2 (+ residual) in one launch (mlp_fused.hip); bf16 / fp16, d in {96, 192}."""
-        assert t.dense and res.dense and y.dense and t.code in (L.BF16, L.F16) and t.C in (96, 192)
+        assert t.dense and res.dense and y.dense and t.code in (L.BF16, L.F16) and t.C in (96, 192, 384)
         M, D = t.N * t.H * t.W, t.C
         args = (t.ptr, res.ptr, w1.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), y.ptr, M, D, t.code)
         self.launches.append(Launch(self.lib.mtbt_convnext_mlp_fused_dt, args, name, (t.buf, res.buf, w1, b1, w2p, b2, y.buf),

@@ -323,6 +323,14 @@ class _Lowering:
         self.p.conv(x, self.W(pw * scale[:, None]), y, shift=self.F(shift), act=L.ACT_ELU, name=name)
         return y
 
+    @staticmethod
+    def fused_dims():
+        """ConvNeXt widths whose MLP runs as ONE launch (mlp_fused.hip).  d = 384 is built and tested too (MTBT_FUSED_DIMS="96:192:384") but
+        measured equal to the two GEMMs inside the step (7.62 vs 7.61 ms, profiles/r02_notes.md): at one wave per SIMD its GELU and
+        fragment reads are no longer covered by a partner wave."""
+        env = os.environ.get("MTBT_FUSED_DIMS")
+        return tuple(int(v) for v in env.replace(":", ",").split(",")) if env else (96, 192)
+
     def subbatch(self, stage: int, a: Act) -> int:
         """Images per depth-first pass of a ConvNeXt stage.  Measured (bench.py --ab MTBT_SUBBATCH=...): keeping the 4d-wide
         intermediate Infinity-Cache-resident by running 2-8 images at a time does NOT pay on MI355X at batch 16 -- the
@@ -373,7 +381,7 @@ class _Lowering:
             sb = self.subbatch(si, a)
             out_full = self.p.new(a.N, a.H, a.W, d, self.code)
             t = self.p.new(sb, a.H, a.W, d, self.code)
-            fused = self.code in (L.BF16, L.F16) and d in (96, 192) and sb == a.N and os.environ.get("MTBT_FUSED_MLP", "1") == "1"
+            fused = self.code in (L.BF16, L.F16) and d in self.fused_dims() and sb == a.N and os.environ.get("MTBT_FUSED_MLP", "1") == "1"
             h = None if fused else self.p.new(sb, a.H, a.W, 4 * d, self.code)
             pp_ = [self.p.new(sb, a.H, a.W, d, self.code) for _ in range(2)] if len(st.blocks) > 1 else []
             consts = []

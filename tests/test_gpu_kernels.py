@@ -267,7 +267,7 @@ def test_gap_fc(dtype):
     assert (y.cpu() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("D,M", [(96, 1000), (192, 517), (96, 256)])
+@pytest.mark.parametrize("D,M", [(96, 1000), (192, 517), (96, 256), (384, 128 * 3), (384, 128 * 7 + 37)])
 def test_convnext_mlp_fused(D, M):
     """mlp_fused.hip against torch: res + fc2'(GELU(fc1(t))) with bf16 storage of t, the hidden activations and the weights
     (the unfused path rounds at the same points); ragged M exercises the tail masking."""
