@@ -64,3 +64,40 @@ def test_gloo_world_size_2_gradient_exchange(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert sorted(l for o in outs for l in o.splitlines() if l.startswith("RANK")) == ["RANK0 ok", "RANK1 ok"]
+
+
+def test_gradient_arena_layouts_and_unused_parameter_bucket():
+    """train.make_arena (no GPU needed): every trainable parameter has a slot whose kernel-layout view maps back to the parameter's own shape
+    (4-D conv weights channels-last, depthwise taps tap-major, the ConvTranspose, the zero-padded class conv), and the parameters the loss never
+    reaches (Segment cv2 / cv3 / cv4) form leading bucket(s) of their own that the data-parallel step neither reduces nor steps."""
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO
+    from multitask_bonetumor_yolo_amd.train import make_arena
+    from multitask_bonetumor_yolo_amd.trainstep import UNUSED_BY_THE_LOSS
+    m = ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)
+    arena, gview, n_tail = make_arena(m, "cpu", UNUSED_BY_THE_LOSS)
+    names = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert set(arena.views) == names
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        v = arena.views[n]
+        pv = gview[n](v) if gview[n] is not None else v
+        assert tuple(pv.shape) == tuple(p.shape), n
+        assert pv.untyped_storage().data_ptr() == v.untyped_storage().data_ptr()          # a VIEW of the bucket, not a copy
+        assert v.data_ptr() % 16 == 0
+    w = m.backbone.c2f_p3.m[0].cv1.conv.weight                                      # [128,128,3,3] -> slot [K,R,S,C]
+    assert tuple(arena.views["backbone.c2f_p3.m.0.cv1.conv.weight"].shape) == (128, 3, 3, 128)
+    assert tuple(arena.views["detect.cv3.0.2.weight"].shape) == (32, 1, 1, 256)       # nc = 2 rows padded to 32
+    assert tuple(arena.views["backbone.body.stages_0.blocks.0.conv_dw.weight"].shape) == (49, 96)
+    assert n_tail >= 1
+    tail = {n for lay in arena.layout[:n_tail] for n, _, _ in lay}
+    assert tail and all(n.startswith(UNUSED_BY_THE_LOSS) for n in tail)
+    rest = {n for lay in arena.layout[n_tail:] for n, _, _ in lay}
+    assert not any(n.startswith(UNUSED_BY_THE_LOSS) for n in rest)
+    # the same layout twice (the parameter buckets and the gradient buckets of TrainStep must coincide)
+    arena2, _, n_tail2 = make_arena(m, "cpu", UNUSED_BY_THE_LOSS)
+    assert [b.numel() for b in arena.buckets] == [b.numel() for b in arena2.buckets] and n_tail == n_tail2
+    # permuted parameter views round-trip values (what re-homing relies on)
+    v = arena.views["backbone.c2f_p3.m.0.cv1.conv.weight"]
+    gview["backbone.c2f_p3.m.0.cv1.conv.weight"](v).copy_(w.detach())
+    assert torch.equal(v.permute(0, 3, 1, 2), w.detach())
