@@ -332,6 +332,12 @@ int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R
 int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
                     int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same plus the bias gradient dbias[k] (+)= sum_p dy[p][k] (`Conv2d.bias.grad`, `Linear.bias.grad`, and the sum_p dy the layer-scale
+ * gradient needs) from the dY fragments the kernel holds anyway: the workgroups of the first input-channel tile and tap multiply them
+ * with a fragment of ones -- no separate pass over dy. */
+int mtbt_conv_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int K, int R, int S, int pad,
+                         int stride, int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride,
+                         int dtype, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Pointwise pieces of the backward pass.  mtbt_act_backward: dz[i] = dy[i] * act'(z[i]) for MTBT_ACT_* (z = the PRE-activation the
  * training forward keeps; n % 8 == 0; dtype f32 or bf16 for all three arrays).  mtbt_channel_sum: out[c] (+)= sum_p x[p][c] (* x2[p][c]
@@ -353,12 +359,23 @@ int mtbt_channel_affine2(const void* x1, const void* x2, const float* a, const f
 int mtbt_layernorm_backward_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, void* xhat, int64_t pixels, int C,
                                  int dtype, int accumulate /* != 0: dx += (dx already holds another consumer's gradient) */, void* stream);
 
+/* The same in ONE pass together with the parameter gradients (the training plan's form): dx (+)= ...; dgamma (+)= sum_p dy * xhat;
+ * dbeta (+)= sum_p dy.  Per-wave partial rows in `workspace` (>= mtbt_layernorm_backward_params_workspace_bytes), summed in a fixed
+ * order.  No xhat tensor, no separate channel-sum passes over dy. */
+int64_t mtbt_layernorm_backward_params_workspace_bytes(int64_t pixels, int C);
+int mtbt_layernorm_backward_params_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, int64_t pixels, int C, int dtype,
+                                        int accumulate_dx, float* dgamma, float* dbeta, int accumulate_params, void* workspace,
+                                        int64_t workspace_bytes, void* stream);
+
 /* Weight gradient of a depthwise k x k convolution (stride 1, pad k/2; k = 3 or 7): dw[tap][c] (fp32, the forward tap layout [k*k][C])
- * (+)= sum_p dy[p][c] * x[p shifted by the tap][c]; x, dy dense [N,H,W,C], f32 or bf16.  Deterministic.  (One pass per filter
- * row: dy is read once and x k times per row.) */
+ * (+)= sum_p dy[p][c] * x[p shifted by the tap][c]; x, dy dense [N,H,W,C], f32 or bf16.  Deterministic.  (Persistent workgroups over
+ * 8 x 8-pixel tiles: input halo and dy tile staged in LDS, the k*k tap accumulators in registers across tiles.) */
 int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize);
 int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate, void* workspace,
                       int64_t workspace_bytes, void* stream);
+/* the same plus dbias[c] (+)= sum_p dy[p][c] from the same launch */
+int mtbt_dwconv_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused AdamW step over a flat fp32 bucket: torch.optim.AdamW as the reference trainer configures it
  * (running_main_v3.py:732-734: lr, weight_decay 0.0005, default betas / eps), torch's single-tensor operation order, in place.

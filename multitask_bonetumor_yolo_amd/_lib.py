@@ -111,14 +111,20 @@ SYMBOLS = {
     "mtbt_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 7),
     "mtbt_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
+    "mtbt_conv_wgrad_bias": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_int64, C.c_void_p]),
     "mtbt_act_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_channel_sum_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "mtbt_channel_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "mtbt_channel_affine2": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_layernorm_backward_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_layernorm_backward_params_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "mtbt_layernorm_backward_params_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mtbt_dwconv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 5),
     "mtbt_dwconv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_dwconv_wgrad_bias": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "mtbt_adamw_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     "mtbt_sgd_step": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_float] * 4 + [C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "mtbt_sumsq_workspace_bytes": (C.c_int64, []),

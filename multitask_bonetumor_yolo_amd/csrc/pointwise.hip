@@ -1,6 +1,7 @@
 // Bandwidth-bound kernels of the forward path (NHWC, 16-byte accesses, fp32 arithmetic):
 // ConvNeXt stem (4x4/4 conv + LayerNorm2d), LayerNorm over channels, BiFPN weighted fusion with resampling, GAP + Linear, casts.
 #include "common.h"
+#include "rowreduce.h"
 
 namespace {
 
@@ -291,6 +292,109 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restric
   }
 }
 
+// LayerNorm backward WITH the parameter gradients: a wave walks LNB_ITERS consecutive groups of its 64/LP pixels and keeps, per lane,
+// the running sums of dy * xhat (d gamma) and dy (d beta) of its channels; at the end the pixel groups of the wave are folded by
+// shuffles and ONE partial row [d beta | d gamma] per wave goes to the workspace (second level: channel_sum_final_pitch).  Saves the
+// xhat tensor (a write and two reads) and two channel-sum passes over dy per LayerNorm.
+constexpr int LNB_ITERS = 64;   // at most; fewer when the tensor is small (keep >= ~4096 waves in flight)
+static inline int lnb_iters(long pixels, int ppw) {
+  long it = pixels / ((long)ppw * 4096);
+  return (int)(it < 1 ? 1 : (it > LNB_ITERS ? LNB_ITERS : it));
+}
+
+template <typename T, int MAXV, int LP>
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w, float eps,
+                                                                   T* __restrict__ dx, long pixels, int C, int accumulate, float* __restrict__ partial,
+                                                                   int iters) {
+  constexpr int PPW = 64 / LP;
+  const int lane = threadIdx.x & 63, gl = lane % LP;
+  const long wave_id = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int CH8 = C >> 3;
+  float sg[MAXV][8], sb[MAXV][8], gw[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = gl + i * LP;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sg[i][e] = 0.f; sb[i][e] = 0.f; gw[i][e] = 0.f; }
+    if (ch < CH8) ld8<float>(w + ch * 8, gw[i]);
+  }
+  for (int it = 0; it < iters; ++it) {
+    const long pix = (wave_id * iters + it) * PPW + lane / LP;
+    const bool live = pix < pixels;                     // (whole groups)
+    float v[MAXV][8], g[MAXV][8], d[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int ch = gl + i * LP;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = 0.f; d[i][e] = 0.f; }
+      if (live && ch < CH8) {
+        ld8<T>(x + pix * C + ch * 8, v[i]);
+        ld8<T>(dy + pix * C + ch * 8, d[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mean = group_sum<LP>(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int ch = gl + i * LP;
+      if (live && ch < CH8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float t = v[i][e] - mean; q += t * t; }
+      }
+    }
+    const float rstd = rsqrtf(group_sum<LP>(q) / C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int ch = gl + i * LP;
+      if (live && ch < CH8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[i][e] = (v[i][e] - mean) * rstd;       // xhat
+          sg[i][e] += d[i][e] * v[i][e];
+          sb[i][e] += d[i][e];
+          g[i][e] = d[i][e] * gw[i][e];
+          s1 += g[i][e];
+          s2 += g[i][e] * v[i][e];
+        }
+      }
+    }
+    const float m1 = group_sum<LP>(s1) / C, m2 = group_sum<LP>(s2) / C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int ch = gl + i * LP;
+      if (live && ch < CH8) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - v[i][e] * m2);
+        if (accumulate) {
+          float old[8];
+          ld8<T>(dx + pix * C + ch * 8, old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        st8<T>(dx + pix * C + ch * 8, o);
+      }
+    }
+  }
+  // fold the wave's 64/LP pixel groups (same channels in lanes gl, gl + LP, ...) and write one row per wave
+  float* row = partial + wave_id * 2 * C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int ch = gl + i * LP;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = sb[i][e], b = sg[i][e];
+#pragma unroll
+      for (int o = LP; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (lane < LP && ch < CH8) { row[ch * 8 + e] = a; row[C + ch * 8 + e] = b; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BiFPN fusion node: thread = (output pixel, 8-channel chunk).
 // Bilinear x2 (align_corners=False): src = (dst+.5)/2-.5 clamped at 0; i0=floor, i1=min(i0+1,last).
@@ -572,6 +676,49 @@ extern "C" int mtbt_cast(const void* src, void* dst, int64_t n, int sd, int dd, 
   else if (sd == MTBT_F32 && dd == MTBT_F16) hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (f16_t*)dst, (long)n);
   else if (sd == MTBT_F16 && dd == MTBT_F32) hipLaunchKernelGGL((cast_kernel<f16_t, float>), dim3(g), dim3(256), 0, s, (const f16_t*)src, (float*)dst, (long)n);
   else return MTBT_EINVAL;
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int64_t mtbt_layernorm_backward_params_workspace_bytes(int64_t pixels, int C) {
+  if (pixels <= 0 || C <= 0) return 0;
+  const int CH8 = C / 8;
+  const int LP = CH8 <= 16 ? 16 : (CH8 <= 32 ? 32 : 64);
+  const int64_t per = (int64_t)lnb_iters(pixels, 64 / LP) * (64 / LP);
+  const int64_t waves = (pixels + per - 1) / per;
+  return ((waves + 3) / 4 * 4) * 2 * (int64_t)C * (int64_t)sizeof(float);
+}
+
+// LayerNorm backward over the channels of every pixel plus the parameter gradients in the same pass:
+//   dx (+)= rstd (g - mean_c g - xhat mean_c(g xhat)), g = dy gamma;   dgamma (+)= sum_p dy xhat;   dbeta (+)= sum_p dy
+extern "C" int mtbt_layernorm_backward_params_nhwc(const void* x, const void* dy, const float* w, float eps, void* dx, int64_t pixels, int C, int dtype,
+                                                   int accumulate_dx, float* dgamma, float* dbeta, int accumulate_params, void* workspace,
+                                                   int64_t workspace_bytes, void* stream) {
+  if (!x || !dy || !w || !dx || !dgamma || !dbeta || !workspace || pixels <= 0 || C <= 0 || C % 8 || C > 2048) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || !aligned16(w) || !aligned16(workspace)) return MTBT_EALIGN;
+  if (workspace_bytes < mtbt_layernorm_backward_params_workspace_bytes(pixels, C)) return MTBT_EWORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int CH8 = C / 8;
+  const int LP = CH8 <= 16 ? 16 : (CH8 <= 32 ? 32 : 64);
+  const int iters = lnb_iters(pixels, 64 / LP);
+  const long waves = (pixels + (long)iters * (64 / LP) - 1) / ((long)iters * (64 / LP));
+  const long blocks = (waves + 3) / 4;
+  if (blocks > 0x7fffffffL) return MTBT_EINVAL;
+  float* partial = reinterpret_cast<float*>(workspace);
+#define LNP_LAUNCH(T, MAXV, LPV) \
+  hipLaunchKernelGGL((layernorm_bwd_params_kernel<T, MAXV, LPV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, w, eps, (T*)dx, \
+                     (long)pixels, C, accumulate_dx, partial, iters)
+#define LNP_BY_C(T) \
+  do { if (LP == 16) LNP_LAUNCH(T, 1, 16); else if (LP == 32) LNP_LAUNCH(T, 1, 32); else if (CH8 <= 64) LNP_LAUNCH(T, 1, 64); \
+       else if (CH8 <= 128) LNP_LAUNCH(T, 2, 64); else LNP_LAUNCH(T, 4, 64); } while (0)
+  if (dtype == MTBT_F32) LNP_BY_C(float);
+  else if (dtype == MTBT_BF16) LNP_BY_C(bf16_t);
+  else return MTBT_EINVAL;
+#undef LNP_BY_C
+#undef LNP_LAUNCH
+  const int rows = (int)(blocks * 4);     // (waves past the last pixel write zero rows)
+  hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, rows, 2 * C, 0, C, dbeta, accumulate_params);
+  hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, rows, 2 * C, C, C, dgamma, accumulate_params);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

@@ -80,7 +80,7 @@ template <> __device__ __forceinline__ f32p ld_pair<bf16_t>(const char* p) {
 
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
-                                                            float* __restrict__ partial /* [slots * 4][KS*KS*C] */) {
+                                                            float* __restrict__ partial /* [slots * 4][(KS*KS + 1) * C]: taps, then sum_p dy */) {
   constexpr int PAD = KS / 2, TS = 8, IW = TS + KS - 1, ES = (int)sizeof(T), PIXB = 128 * ES, EPC = 16 / ES, PARTS = PIXB / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xt = smem;                       // [IW*IW][128] T
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
   const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
   const long ntiles = (long)N * tiles_y * tiles_x;
   const bool active = lane * 2 < cc;
-  f32p acc[KS * KS];
+  f32p acc[KS * KS], accb = f32p{0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) acc[t] = f32p{0.f, 0.f};
   for (long tl = slot; tl < ntiles; tl += nslots) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
         const int row = 2 * wave + a;
         f32p g[TS];
 #pragma unroll
-        for (int i = 0; i < TS; ++i) g[i] = ld_pair<T>(dt + (row * TS + i) * PIXB + lane * 2 * ES);
+        for (int i = 0; i < TS; ++i) { g[i] = ld_pair<T>(dt + (row * TS + i) * PIXB + lane * 2 * ES); accb += g[i]; }   // (bias gradient: sum_p dy)
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
           f32p in[IW];
@@ -138,10 +138,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
   }
   // partial row (slot, wave): the workgroups of one slot (one per chunk) write disjoint column ranges of the same rows, so every row
   // is complete without any zero fill
-  float* dst = partial + ((long)slot * 4 + wave) * KS * KS * C;
+  float* dst = partial + ((long)slot * 4 + wave) * (KS * KS + 1) * C;
   if (active) {
 #pragma unroll
     for (int t = 0; t < KS * KS; ++t) *reinterpret_cast<f32p*>(dst + (long)t * C + cb + lane * 2) = acc[t];
+    *reinterpret_cast<f32p*>(dst + (long)KS * KS * C + cb + lane * 2) = accb;
   }
 }
 
@@ -222,11 +223,11 @@ static int dw_wgrad_blocks(int N, int H, int W, int C) {
 
 extern "C" int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0) return 0;
-  return (int64_t)(dw_wgrad_blocks(N, H, W, C) / ((C + 127) / 128)) * 4 * ksize * ksize * C * (int64_t)sizeof(float);
+  return (int64_t)(dw_wgrad_blocks(N, H, W, C) / ((C + 127) / 128)) * 4 * (ksize * ksize + 1) * C * (int64_t)sizeof(float);
 }
 
-extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
+static int dw_wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (ksize != 3 && ksize != 7)) return MTBT_EINVAL;
   if (dtype != MTBT_BF16 && dtype != MTBT_F32) return MTBT_EINVAL;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return MTBT_EALIGN;
@@ -247,7 +248,21 @@ extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N
   if (dtype == MTBT_BF16) { if (ksize == 7) DWT(bf16_t, 7); else DWT(bf16_t, 3); }
   else { if (ksize == 7) DWT(float, 7); else DWT(float, 3); }
 #undef DWT
-  hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, (blocks / chunks) * 4, n, dw, accumulate);
+  const int rows = (blocks / chunks) * 4, pitch = n + C;
+  hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, rows, pitch, 0, n, dw, accumulate);
+  if (dbias) hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, rows, pitch, n, C, dbias, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
+}
+
+extern "C" int mtbt_dwconv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  return dw_wgrad_entry(x, dy, dw, nullptr, N, H, W, C, ksize, dtype, accumulate, workspace, workspace_bytes, stream);
+}
+
+// The same plus the bias gradient dbias[c] (+)= sum_p dy[p][c] (`conv_dw.bias.grad`), from the dy tile the kernel stages anyway.
+extern "C" int mtbt_dwconv_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int ksize, int dtype,
+                                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dbias) return MTBT_EINVAL;
+  return dw_wgrad_entry(x, dy, dw, dbias, N, H, W, C, ksize, dtype, accumulate, workspace, workspace_bytes, stream);
 }

@@ -65,4 +65,15 @@ __global__ __launch_bounds__(256) void channel_sum_final(const float* __restrict
   if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
+// the same over a [blocks][pitch] partial matrix, columns [c0, c0 + C)
+__global__ __launch_bounds__(256) void channel_sum_final_pitch(const float* __restrict__ partial, int blocks, int pitch, int c0, int C, float* __restrict__ out,
+                                                               int accumulate) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = lane; b < blocks; b += 64) s += partial[(long)b * pitch + c0 + c];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
 }  // namespace

@@ -24,6 +24,7 @@ constexpr int TK = 128, TCH = 128, TPX = 64, LPT = TPX / 16;   // LPT: 16-byte l
 
 struct WgP {
   const bf16_t* x; const bf16_t* dy; float* partial;
+  float* bpartial;    // optional [nsplit][K]: per-slice sums of dy over the pixels (the bias gradient), or NULL
   int N, H, W, C, K, R, S, pad, stride, Ho, Wo;
   long x_bs, dy_bs; int ldx, ldy;
   long P, per;        // pixels, pixels per slice (multiple of TPX)
@@ -42,6 +43,7 @@ __device__ __forceinline__ int tile_off(int row, int col) {   // element offset 
   return row * 128 + (swz_unit(row, col >> 4) << 4) + (col & 15);
 }
 
+template <bool BIAS>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
   __shared__ __attribute__((aligned(16))) bf16_t sdy[TPX * TK];
   __shared__ __attribute__((aligned(16))) bf16_t sx[TPX * TCH];
@@ -65,6 +67,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient for free: the workgroups of (first input-channel tile, first tap) also multiply their dY fragments with a
+  // fragment of ONES -- D[k][j] = sum_p dY[p][k] in every column j (4 extra MFMAs per 16, in 1 / (ctiles * taps) of the workgroups)
+  const bool do_bias = BIAS && p.bpartial != nullptr && ct == 0 && tap == 0 && wc == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
 
   uint4 vdy[LPT], vx[LPT];
   auto fetch = [&](long pb) {   // this thread's 16-byte pieces of the step starting at pixel pb (zeros past the slice / outside the image)
@@ -109,7 +118,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb)
           acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, B[fb]), acc[fa][fb], 0, 0, 0);
+      if (BIAS && do_bias) {   // (wave-uniform)
+#pragma unroll
+        for (int fa = 0; fa < 4; ++fa)
+          accb[fa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, ones), accb[fa], 0, 0, 0);
+      }
     }
+  }
+  if (BIAS && do_bias && (lane & 15) == 0) {
+#pragma unroll
+    for (int fa = 0; fa < 4; ++fa)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kt * TK + 64 * wk + 16 * fa + 4 * (lane >> 4) + e;
+        if (k < p.K) p.bpartial[(long)split * p.K + k] = accb[fa][e];
+      }
   }
   // lane: output channel kt*128 + 64 wk + 16 fa + 4 (lane / 16) + e, input channel ct*128 + 64 wc + 16 fb + lane % 16
   const long RSC = (long)taps * p.C;
@@ -139,6 +162,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // the whole backward pass can be checked against fp32 autograd. ----
 struct WgPF {
   const float* x; const float* dy; float* partial;
+  float* bpartial;
   int N, H, W, C, K, R, S, pad, stride, Ho, Wo;
   long x_bs, dy_bs; int ldx, ldy;
   long P, per;
@@ -163,6 +187,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgPF p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const bool do_bias = p.bpartial != nullptr && ct == 0 && tap == 0 && tx == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   for (long pb = p0; pb < p1; pb += 16) {
     const long pix = pb + row;
     float4 vd = make_float4(0.f, 0.f, 0.f, 0.f), vx = vd;
@@ -188,6 +214,17 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgPF p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], cv[j], acc[i][j]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[i] += av[i];
+      }
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt * 64 + ty * 4 + i;
+      if (k < p.K) p.bpartial[(long)split * p.K + k] = bsum[i];
     }
   }
   const long RSC = (long)taps * p.C;
@@ -203,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgPF p) {
 // ---- ConvNeXt stem weight gradient: dW[k][c*16 + ky*4 + kx] = sum_p d[p][k] * img[n][c][4 oy + ky][4 ox + kx]  (the 4x4 / stride-4
 // patchify conv on the caller's NCHW fp32 image, main_model.py:21-26 [timm stem_0]).  Persistent workgroups: 64 pixels per step staged in
 // LDS (48-float patches, K gradients), thread (kg, c) accumulates K/4 rows of column c in registers; per-workgroup partials. ----
-template <typename T, int KPT>
+template <typename T>
 __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ d, int N, int H, int W, int K,
                                                          float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -211,11 +248,13 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
   float* dk = patch + 64 * 48;                     // [64][K]
   const int Ho = H / 4, Wo = W / 4;
   const long total = (long)N * Ho * Wo;
-  const int tid = threadIdx.x, c = tid % 48, kg = tid / 48;   // kg in 0..3 owns rows kg*KPT ..
-  const int kmax = min(KPT, K - kg * KPT);                      // rows of this thread inside K (<= 0: none)
-  float acc[KPT];
+  const int tid = threadIdx.x, cg = tid % 12, kg = tid / 12;   // thread = an 8 (rows of dW) x 4 (columns) register block
+  const bool own = kg * 8 < K;
+  float acc[8][4];
 #pragma unroll
-  for (int i = 0; i < KPT; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
     __syncthreads();
     for (int it = tid; it < 64 * 12; it += 192) {
@@ -236,17 +275,23 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
       dk[pix * K + k] = gp < total ? ld_elem<T>(d + gp * K + k) : 0.f;
     }
     __syncthreads();
-    for (int pix = 0; pix < 64; ++pix) {
-      const float pv = patch[pix * 48 + c];
-      const float* dr = dk + pix * K + kg * KPT;
+    if (own) {
+      for (int pix = 0; pix < 64; ++pix) {   // 3 x 16-byte LDS reads for 32 FMAs
+        const float4 pv = *reinterpret_cast<const float4*>(patch + pix * 48 + cg * 4);
+        const float4 d0 = *reinterpret_cast<const float4*>(dk + pix * K + kg * 8), d1 = *reinterpret_cast<const float4*>(dk + pix * K + kg * 8 + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-      for (int i = 0; i < KPT; ++i)
-        if (i < kmax) acc[i] = fmaf(dr[i], pv, acc[i]);
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], pp[j], acc[i][j]);
+      }
     }
   }
+  if (own) {
 #pragma unroll
-  for (int i = 0; i < KPT; ++i)
-    if (i < kmax) partial[(long)blockIdx.x * K * 48 + (long)(kg * KPT + i) * 48 + c] = acc[i];
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<float4*>(partial + (long)blockIdx.x * K * 48 + (long)(kg * 8 + i) * 48 + cg * 4) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  }
 }
 
 int pick_split(int K, int C, int taps, long P) {
@@ -268,12 +313,12 @@ int pick_split(int K, int C, int taps, long P) {
 extern "C" int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return 0;
   // an upper bound for every stride: slices never outnumber those of the stride-1 case (fewer dY pixels)
-  return (int64_t)pick_split(K, C, R * S, (long)N * H * W) * K * R * S * C * (int64_t)sizeof(float);
+  return (int64_t)pick_split(K, C, R * S, (long)N * H * W) * ((int64_t)K * R * S * C + K) * (int64_t)sizeof(float);
 }
 
-extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
-                               int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
-                               int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
+                       int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
+                       int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return MTBT_EINVAL;
   if (dtype != MTBT_BF16 && dtype != MTBT_F32) return MTBT_EINVAL;
   const int epc = dtype == MTBT_BF16 ? 8 : 4;   // elements per 16-byte piece
@@ -284,12 +329,14 @@ extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, 
   const long P = (long)N * Ho * Wo;
   const int nsplit = pick_split(K, C, R * S, P);
   // the slices actually launched decide the workspace (a padding > (R-1)/2 makes Ho*Wo exceed H*W, beyond the documented bound)
-  if (workspace_bytes < (int64_t)nsplit * K * R * S * C * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+  if (workspace_bytes < (int64_t)nsplit * ((int64_t)K * R * S * C + K) * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+  float* bpartial = dbias ? reinterpret_cast<float*>(workspace) + (int64_t)nsplit * K * R * S * C : nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long n = (long)K * R * S * C;
   if (dtype == MTBT_F32) {
     WgPF p;
     p.x = reinterpret_cast<const float*>(x); p.dy = reinterpret_cast<const float*>(dy); p.partial = reinterpret_cast<float*>(workspace);
+    p.bpartial = bpartial;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.pad = pad; p.stride = stride; p.Ho = Ho; p.Wo = Wo;
     p.x_bs = x_batch_stride; p.dy_bs = dy_batch_stride; p.ldx = x_pixel_stride; p.ldy = dy_pixel_stride;
     p.P = P; p.nsplit = nsplit;
@@ -299,11 +346,13 @@ extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, 
     if (blocks > 0x7fffffffL) return MTBT_EINVAL;
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.partial, dw, n, p.nsplit, accumulate);
+    if (dbias) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, bpartial, dbias, (long)K, p.nsplit, accumulate);
     MTBT_LAUNCH_CHECK();
     return MTBT_OK;
   }
   WgP p;
   p.x = reinterpret_cast<const bf16_t*>(x); p.dy = reinterpret_cast<const bf16_t*>(dy); p.partial = reinterpret_cast<float*>(workspace);
+  p.bpartial = bpartial;
   p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.pad = pad; p.stride = stride; p.Ho = Ho; p.Wo = Wo;
   p.x_bs = x_batch_stride; p.dy_bs = dy_batch_stride; p.ldx = x_pixel_stride; p.ldy = dy_pixel_stride;
   p.P = P;
@@ -312,19 +361,37 @@ extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, 
   p.ktiles = (K + TK - 1) / TK; p.ctiles = (C + TCH - 1) / TCH;
   const long blocks = (long)p.nsplit * R * S * p.ktiles * p.ctiles;
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  if (dbias) hipLaunchKernelGGL(wgrad_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.partial, dw, n, p.nsplit, accumulate);
+  if (dbias) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, bpartial, dbias, (long)K, p.nsplit, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
+}
+
+extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
+                               int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
+                               int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return wgrad_entry(x, dy, dw, nullptr, N, H, W, C, K, R, S, pad, stride, x_batch_stride, x_pixel_stride, dy_batch_stride, dy_pixel_stride, dtype,
+                     accumulate, workspace, workspace_bytes, stream);
+}
+
+// The same plus the BIAS gradient dbias[k] (+)= sum_p dy[p][k] from the dY fragments the kernel holds anyway (no extra pass over dy).
+extern "C" int mtbt_conv_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int K, int R, int S, int pad,
+                                    int stride, int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride,
+                                    int dtype, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!dbias) return MTBT_EINVAL;
+  return wgrad_entry(x, dy, dw, dbias, N, H, W, C, K, R, S, pad, stride, x_batch_stride, x_pixel_stride, dy_batch_stride, dy_pixel_stride, dtype,
+                     accumulate, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t mtbt_stem_wgrad_workspace_bytes(int K) { return K <= 0 ? 0 : (int64_t)512 * K * 48 * (int64_t)sizeof(float); }
 
 // Weight gradient of the ConvNeXt stem conv (4x4, stride 4, 3 -> K channels) on the caller's NCHW fp32 image: dw [K][48] (torch's
-// [K,3,4,4] flattened) (+)= sum over the N*(H/4)*(W/4) output pixels of d[p][k] * patch(p); d dense [pixels][K] in `dtype`.  K % 4 == 0, K <= 128.
+// [K,3,4,4] flattened) (+)= sum over the N*(H/4)*(W/4) output pixels of d[p][k] * patch(p); d dense [pixels][K] in `dtype`.  K % 8 == 0, K <= 128.
 extern "C" int mtbt_stem_wgrad(const float* x, const void* d, float* dw, int N, int H, int W, int K, int dtype, int accumulate, void* workspace,
                                int64_t workspace_bytes, void* stream) {
-  if (!x || !d || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || K <= 0 || K % 4 || K > 128) return MTBT_EINVAL;
+  if (!x || !d || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || K <= 0 || K % 8 || K > 128) return MTBT_EINVAL;
   if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
   if (!aligned16(x) || !aligned16(workspace)) return MTBT_EALIGN;
   if (workspace_bytes < mtbt_stem_wgrad_workspace_bytes(K)) return MTBT_EWORKSPACE;
@@ -334,9 +401,8 @@ extern "C" int mtbt_stem_wgrad(const float* x, const void* d, float* dw, int N, 
   const size_t lds = (size_t)64 * (48 + K) * sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
-#define SW(T, KPT) hipLaunchKernelGGL((stem_wgrad_kernel<T, KPT>), dim3((unsigned)blocks), dim3(192), lds, st, x, (const T*)d, N, H, W, K, partial)
-  if (K == 96) { if (dtype == MTBT_F32) SW(float, 24); else SW(bf16_t, 24); }
-  else { if (dtype == MTBT_F32) SW(float, 32); else SW(bf16_t, 32); }
+#define SW(T) hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3((unsigned)blocks), dim3(192), lds, st, x, (const T*)d, N, H, W, K, partial)
+  if (dtype == MTBT_F32) SW(float); else SW(bf16_t);
 #undef SW
   const int n = K * 48;
   hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, (int)blocks, n, dw, accumulate);

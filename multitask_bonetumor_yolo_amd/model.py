@@ -624,14 +624,21 @@ class _Base(nn.Module):
             # the head branches (3 levels x detect / segment / cv4 + Proto) are independent: no buffer recycling between
             # them, so the lane scheduler (engine.Plan.schedule) sees no false write-after-read dependencies
             lo.p.pool.reuse = lo.p.pool.reuse and os.environ.get("MTBT_HEAD_REUSE", "0") == "1"
+            # order: Detect first (its maps start the box decode + NMS on a side stream), then the mask coefficients and prototypes (with
+            # the kept boxes they start the mask assembly, which then runs UNDER Segment's own box / class branches and the cls head)
             det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
-            seg_maps = lo.det_branch(feats, self.segment, "segment")
+            if det_maps is None:
+                seg_maps = lo.det_branch(feats, self.segment, "segment")
             mc, protos = lo.seg_extras(feats, self.segment)
+            if det_maps is not None:
+                seg_maps = lo.det_branch(feats, self.segment, "segment")
             logits = lo.cls_head(n5)
         c = _Compiled(lo.p, xs, det_maps, seg_maps, mc, protos, logits, sig)
         # launches that write the maps the box decode reads: the post-process forks as soon as these are done
         keys = {m.buf.untyped_storage().data_ptr() for m in (det_maps if det_maps is not None else seg_maps)}
         c.det_marks = [i for i, l in enumerate(lo.p.launches) if any(w[0] in keys for w in l.writes)]
+        mkeys = {mc.untyped_storage().data_ptr(), protos.buf.untyped_storage().data_ptr()}
+        c.mask_marks = [i for i, l in enumerate(lo.p.launches) if any(w[0] in mkeys for w in l.writes)]
         c.train_bns = lo.train_bns
         cache[key] = c
         return c
@@ -666,18 +673,24 @@ class _Base(nn.Module):
             maps = c.det_maps if c.det_maps is not None else c.seg_maps
             main = torch.cuda.current_stream(x.device)
             side = side_stream or self.__dict__.setdefault("_side_stream", torch.cuda.Stream(device=x.device))
-            ready = c.plan.run(marks=c.det_marks)
+            ready = c.plan.run(marks={"det": c.det_marks, "mask": c.mask_marks if masks else []})
+            mk = None
             with torch.cuda.stream(side):
-                for ev in ready:
+                for ev in ready["det"]:
                     side.wait_event(ev)
                 d = pp.decode_boxes([m.nchw() for m in maps], img_size, want_scores=False)
                 k = pp.nms_batched(d["boxes"], d["best_score"], d["best_label"], float(img_size), conf_th, iou_th, top_k)
+                early = masks and os.environ.get("MTBT_MASK_OVERLAP", "1") == "1"     # (=0: A/B switch, masks after the join as in round 1)
+                if early:     # as soon as the coefficients and prototypes exist: under the launches that are still running on the plan's lanes
+                    for ev in ready["mask"]:
+                        side.wait_event(ev)
+                    mk, _ = pp.assemble_masks(c.protos.nchw(), c.mc.permute(0, 2, 1), k["keep_anchor"], k["counts"], (img_size, img_size))
             main.wait_stream(side)
             out = {"boxes": k["boxes"], "scores": k["scores"], "labels": k["labels"], "counts": k["counts"],
                    "keep_idx": k["keep_idx"], "keep_anchor": k["keep_anchor"], "n_cand": k["n_cand"]}
             if masks:
-                out["masks"], _ = pp.assemble_masks(c.protos.nchw(), c.mc.permute(0, 2, 1), k["keep_anchor"], k["counts"], (img_size, img_size))
-            for t in (d["boxes"], d["best_score"], d["best_label"]):
+                out["masks"] = mk if mk is not None else pp.assemble_masks(c.protos.nchw(), c.mc.permute(0, 2, 1), k["keep_anchor"], k["counts"], (img_size, img_size))[0]
+            for t in [d["boxes"], d["best_score"], d["best_label"]] + [v for v in out.values() if isinstance(v, torch.Tensor)]:
                 t.record_stream(main)
             return self._infer_dict(c, own=own_outputs), out
         finally:

@@ -92,13 +92,18 @@ class TPlan(Plan):
         self.raw(self.lib.mtbt_bn_backward_nhwc, args, name, keep=(dy.buf, x.buf, stats, dx.buf, dgamma, dbeta, bn), reads=[dy, x, stats],
                  writes=[dx, dgamma, dbeta, self.ws])
 
-    def wgrad(self, x: Act, dy: Act, out: torch.Tensor, *, R, S, pad, stride=1, name="wgrad"):
+    def wgrad(self, x: Act, dy: Act, out: torch.Tensor, *, R, S, pad, stride=1, dbias: Optional[torch.Tensor] = None, name="wgrad"):
+        """dW (and, with `dbias`, sum_p dy -- the bias gradient, from the same launch)."""
         assert x.code == dy.code and x.N == dy.N and out.dtype == torch.float32 and out.is_contiguous()
         assert out.numel() == dy.C * R * S * x.C, (out.shape, dy.C, R, S, x.C)
+        assert dbias is None or (dbias.numel() == dy.C and dbias.dtype == torch.float32)
         nbytes = self.lib.mtbt_conv_wgrad_workspace_bytes(x.N, max(x.H, dy.H), max(x.W, dy.W), x.C, dy.C, R, S)
-        args = (x.ptr, dy.ptr, out.data_ptr(), x.N, x.H, x.W, x.C, dy.C, R, S, pad, stride, x.batch_stride, x.ld, dy.batch_stride, dy.ld, x.code, 0,
-                self._ws(nbytes), nbytes)
-        self.raw(self.lib.mtbt_conv_wgrad, args, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.ws])
+        tail = (x.N, x.H, x.W, x.C, dy.C, R, S, pad, stride, x.batch_stride, x.ld, dy.batch_stride, dy.ld, x.code, 0, self._ws(nbytes), nbytes)
+        if dbias is None:
+            self.raw(self.lib.mtbt_conv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.ws])
+        else:
+            self.raw(self.lib.mtbt_conv_wgrad_bias, (x.ptr, dy.ptr, out.data_ptr(), dbias.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out, dbias),
+                     reads=[x, dy], writes=[out, dbias, self.ws])
         self.launches[-1].flops = 2.0 * dy.N * dy.H * dy.W * dy.C * R * S * x.C
 
     def channel_sum(self, x: Act, out: torch.Tensor, times: Optional[Act] = None, name="channel_sum"):
@@ -110,11 +115,15 @@ class TPlan(Plan):
         self.raw(self.lib.mtbt_channel_sum, args, name, keep=(x.buf, times.buf if times is not None else None, out), reads=[x, times],
                  writes=[out, self.ws])
 
-    def ln_backward(self, x: Act, dy: Act, gamma: torch.Tensor, eps, dx: Act, xhat: Act, accumulate: bool, name):
-        assert x.dense and dy.dense and dx.dense and xhat.dense
-        args = (x.ptr, dy.ptr, gamma.data_ptr(), C.c_float(eps), dx.ptr, xhat.ptr, x.N * x.H * x.W, x.C, x.code, int(accumulate))
-        self.raw(self.lib.mtbt_layernorm_backward_nhwc, args, name, keep=(x.buf, dy.buf, gamma, dx.buf, xhat.buf), reads=[x, dy] + ([dx] if accumulate else []),
-                 writes=[dx, xhat])
+    def ln_backward_params(self, x: Act, dy: Act, gamma: torch.Tensor, eps, dx: Act, accumulate: bool, dgamma: torch.Tensor, dbeta: torch.Tensor, name):
+        """LayerNorm backward with d gamma / d beta from the same pass (no xhat tensor, no channel-sum passes)."""
+        assert x.dense and dy.dense and dx.dense
+        P = x.N * x.H * x.W
+        nbytes = self.lib.mtbt_layernorm_backward_params_workspace_bytes(P, x.C)
+        args = (x.ptr, dy.ptr, gamma.data_ptr(), C.c_float(eps), dx.ptr, P, x.C, x.code, int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), 0,
+                self._ws(nbytes), nbytes)
+        self.raw(self.lib.mtbt_layernorm_backward_params_nhwc, args, name, keep=(x.buf, dy.buf, gamma, dx.buf, dgamma, dbeta),
+                 reads=[x, dy] + ([dx] if accumulate else []), writes=[dx, dgamma, dbeta, self.ws])
 
     def dwconv_t(self, x: Act, w, y: Act, ksize, *, bias=None, lnw=None, lnb=None, eps=0.0, scale=None, shift=None, act=L.ACT_NONE,
                  raw: Optional[Act] = None, res: Optional[Act] = None, name="dwconv"):
@@ -126,11 +135,15 @@ class TPlan(Plan):
         n = x.N * x.H * x.W * x.C
         self.launches[-1].flops, self.launches[-1].bytes = 2.0 * n * ksize * ksize, 2.0 * n * ESIZE[x.code]
 
-    def dw_wgrad(self, x: Act, dy: Act, out: torch.Tensor, ksize, name):
+    def dw_wgrad(self, x: Act, dy: Act, out: torch.Tensor, ksize, name, dbias: Optional[torch.Tensor] = None):
         assert x.dense and dy.dense
         nbytes = self.lib.mtbt_dwconv_wgrad_workspace_bytes(x.N, x.H, x.W, x.C, ksize)
-        args = (x.ptr, dy.ptr, out.data_ptr(), x.N, x.H, x.W, x.C, ksize, x.code, 0, self._ws(nbytes), nbytes)
-        self.raw(self.lib.mtbt_dwconv_wgrad, args, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.ws])
+        tail = (x.N, x.H, x.W, x.C, ksize, x.code, 0, self._ws(nbytes), nbytes)
+        if dbias is None:
+            self.raw(self.lib.mtbt_dwconv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.ws])
+        else:
+            self.raw(self.lib.mtbt_dwconv_wgrad_bias, (x.ptr, dy.ptr, out.data_ptr(), dbias.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out, dbias),
+                     reads=[x, dy], writes=[out, dbias, self.ws])
 
     def copy_strided(self, src_ptr, src_code, sbs, sld, dst: Act, N, pixels, Cc, Cpad, keep, name):
         args = (src_ptr, src_code, sbs, sld, dst.ptr, dst.code, dst.bs, dst.ld, N, pixels, Cc, Cpad)
@@ -404,13 +417,11 @@ class TrainPlan:
             d_raw = self.bwd.new(x.N, x.H, x.W, K, self.code)
             self.bwd.bn_backward(self.G(y), raw, st, bn, act, running, d_raw, self.pg(bn.weight), self.pg(bn.bias), name + ".bn.bwd")
             self.done(y)
-            self.bwd.wgrad(x, d_raw, self.pg(conv.weight), R=k, S=k, pad=k // 2, name=name + ".wgrad")
-            if bias is not None:
-                slot = self.pg(conv.bias)
-                if running:
-                    self.bwd.channel_sum(d_raw, slot, name=name + ".dbias")
-                # batch statistics: sum_p d_raw = 0 EXACTLY (a bias in front of a batch-statistic BatchNorm cannot move the output), so the
-                # slot keeps the arena's zero -- autograd returns rounding noise of the order 1e-9 there
+            # bias gradient: running statistics -> sum_p d_raw, from the weight-gradient launch itself.  Batch statistics: sum_p d_raw = 0
+            # EXACTLY (a bias in front of a batch-statistic BatchNorm cannot move the output), so the slot keeps the arena's zero --
+            # autograd returns rounding noise of the order 1e-9 there
+            slot = self.pg(conv.bias) if bias is not None else None
+            self.bwd.wgrad(x, d_raw, self.pg(conv.weight), R=k, S=k, pad=k // 2, dbias=slot if running else None, name=name + ".wgrad")
             self._dgrad(d_raw, wd, x, k, k // 2, name)
             self.bwd.release(d_raw)
         self.tape.append(bwd)
@@ -428,8 +439,7 @@ class TrainPlan:
             dy = dy_src()
             if dy is None:
                 return
-            self.bwd.wgrad(x, dy, self.pg(conv.weight), R=1, S=1, pad=0, name=name + ".wgrad")
-            self.bwd.channel_sum(dy, self.pg(conv.bias), name=name + ".dbias")
+            self.bwd.wgrad(x, dy, self.pg(conv.weight), R=1, S=1, pad=0, dbias=self.pg(conv.bias), name=name + ".wgrad")
             self._dgrad(dy, wd, x, 1, 0, name)
         self.tape.append(bwd)
 
@@ -527,13 +537,10 @@ class TrainPlan:
         def stem_bwd(a=a, raw0=raw0):
             if not self.has_grad(a):
                 return
-            d_raw, xhat = self.bwd.new(a.N, a.H, a.W, a.C, T), self.bwd.new(a.N, a.H, a.W, a.C, T)
-            ga = self.G(a)
-            self.bwd.ln_backward(raw0, ga, body.stem_1.weight, body.stem_1.eps, d_raw, xhat, False, "stem.ln.bwd")
-            self.bwd.channel_sum(ga, self.pg(body.stem_1.weight), times=xhat, name="stem.ln.dgamma")
-            self.bwd.channel_sum(ga, self.pg(body.stem_1.bias), name="stem.ln.dbeta")
+            d_raw = self.bwd.new(a.N, a.H, a.W, a.C, T)
+            self.bwd.ln_backward_params(raw0, self.G(a), body.stem_1.weight, body.stem_1.eps, d_raw, False, self.pg(body.stem_1.weight),
+                                        self.pg(body.stem_1.bias), "stem.ln.bwd")
             self.done(a)
-            self.bwd.release(xhat)
             self.bwd.channel_sum(d_raw, self.pg(st0.bias), name="stem.dbias")
             nbytes = self.lib.mtbt_stem_wgrad_workspace_bytes(a.C)
             dW = self.pg(st0.weight)
@@ -570,18 +577,14 @@ class TrainPlan:
             if not self.has_grad(nxt):
                 return
             dy = self.G(nxt)
-            self.bwd.wgrad(t, dy, self.pg(cv.weight), R=2, S=2, pad=0, stride=2, name=name + ".1.wgrad")
-            self.bwd.channel_sum(dy, self.pg(cv.bias), name=name + ".1.dbias")
-            d_t, xhat = self.bwd.new(a.N, a.H, a.W, a.C, T), self.bwd.new(a.N, a.H, a.W, a.C, T)
+            self.bwd.wgrad(t, dy, self.pg(cv.weight), R=2, S=2, pad=0, stride=2, dbias=self.pg(cv.bias), name=name + ".1.wgrad")
+            d_t = self.bwd.new(a.N, a.H, a.W, a.C, T)
             self.bwd.conv2(dy, wd, d_t, out_mode=L.OUT_CONVT2X2, name=name + ".1.dgrad")
             self.done(nxt)
             ga = self.G(a)
             acc = self.acc(a)
-            self.bwd.ln_backward(a, d_t, ln.weight, ln.eps, ga, xhat, acc, name + ".0.bwd")
-            self.bwd.channel_sum(d_t, self.pg(ln.weight), times=xhat, name=name + ".0.dgamma")
-            self.bwd.channel_sum(d_t, self.pg(ln.bias), name=name + ".0.dbeta")
+            self.bwd.ln_backward_params(a, d_t, ln.weight, ln.eps, ga, acc, self.pg(ln.weight), self.pg(ln.bias), name + ".0.bwd")
             self.bwd.release(d_t)
-            self.bwd.release(xhat)
         self.tape.append(bwd)
         return nxt
 
@@ -615,6 +618,8 @@ class TrainPlan:
             if not self.has_grad(y):
                 return
             dy = self.G(y)
+            # (sum_p dy and the fc1 bias gradient stay separate channel sums: in these GEMM-shaped weight gradients EVERY workgroup would
+            #  carry the 25 % extra MFMAs of the fused form -- measured +2.0 ms against the 2.8 ms of the two sums)
             self.bwd.channel_sum(dy, ssum, name=name + ".sum_dy")
             self.bwd.wgrad(h, dy, gtmp, R=1, S=1, pad=0, name=name + ".fc2.wgrad")
             dW2, dg, db2 = self.pg(fc2.weight), self.pg(gamma), self.pg(fc2.bias)
@@ -628,14 +633,10 @@ class TrainPlan:
             d_t = self.bwd.new(N, H, W, d, T)
             self.bwd.conv2(d_hpre, w1d, d_t, name=name + ".fc1.dgrad")
             self.bwd.release(d_hpre)
-            d_r, xhat = self.bwd.new(N, H, W, d, T), self.bwd.new(N, H, W, d, T)
-            self.bwd.ln_backward(r, d_t, blk.norm.weight, blk.norm.eps, d_r, xhat, False, name + ".norm.bwd")
-            self.bwd.channel_sum(d_t, self.pg(blk.norm.weight), times=xhat, name=name + ".norm.dgamma")
-            self.bwd.channel_sum(d_t, self.pg(blk.norm.bias), name=name + ".norm.dbeta")
+            d_r = self.bwd.new(N, H, W, d, T)
+            self.bwd.ln_backward_params(r, d_t, blk.norm.weight, blk.norm.eps, d_r, False, self.pg(blk.norm.weight), self.pg(blk.norm.bias), name + ".norm.bwd")
             self.bwd.release(d_t)
-            self.bwd.release(xhat)
-            self.bwd.dw_wgrad(cur, d_r, self.pg(dw), 7, name + ".conv_dw.wgrad")
-            self.bwd.channel_sum(d_r, self.pg(blk.conv_dw.bias), name=name + ".conv_dw.dbias")
+            self.bwd.dw_wgrad(cur, d_r, self.pg(dw), 7, name + ".conv_dw.wgrad", dbias=self.pg(blk.conv_dw.bias))
             # residual: d cur = d y + dwconv^T(d_r) -- grad(y)'s buffer BECOMES grad(cur), the depthwise dgrad accumulates into it
             if self.has_grad(cur):
                 raise NotImplementedError("a ConvNeXt block input with a second consumer")

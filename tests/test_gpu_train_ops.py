@@ -446,3 +446,72 @@ def test_sgd_sumsq_clip_and_scaled_adamw():
         L.check(lib.mtbt_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 5e-4, step, coef.data_ptr(), S()), "adamw")
         torch.cuda.synchronize()
         close(p, ref.detach(), 5e-6, f"adamw step {step}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_with_bias_gradient(dtype):
+    """mtbt_conv_wgrad_bias: dW and sum_p dy (the bias gradient) from one launch -- ragged channel tiles, several slices."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(31)
+    N, H, W, Cc, K, k = 3, 24, 20, 96, 200, 3
+    x = torch.randn(N, Cc, H, W, generator=g).to(dtype).float()
+    dy = torch.randn(N, K, H, W, generator=g).to(dtype).float()
+    w = torch.zeros(K, Cc, k, k, requires_grad=True)
+    b = torch.zeros(K, requires_grad=True)
+    F.conv2d(x, w, b, 1, 1).backward(dy)
+    xa, dya = Act.of(nhwc(x, dtype)), Act.of(nhwc(dy, dtype))
+    out, db = torch.empty(K, k * k * Cc, device=DEV), torch.empty(K, device=DEV)
+    nb = lib.mtbt_conv_wgrad_workspace_bytes(N, H, W, Cc, K, k, k)
+    ws = torch.empty(nb // 4, device=DEV)
+    L.check(lib.mtbt_conv_wgrad_bias(xa.ptr, dya.ptr, out.data_ptr(), db.data_ptr(), N, H, W, Cc, K, k, k, 1, 1, xa.bs, xa.ld, dya.bs, dya.ld, CODE[dtype], 0,
+                                     ws.data_ptr(), nb, S()), "wgrad+bias")
+    torch.cuda.synchronize()
+    close(out, w.grad.permute(0, 2, 3, 1).reshape(K, -1), 3e-4, "dW")
+    close(db, b.grad, 3e-4, "dbias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc,k", [(96, 7), (256, 3), (384, 7)])
+def test_dwconv_wgrad_with_bias_gradient(dtype, Cc, k):
+    lib = L.load()
+    g = torch.Generator().manual_seed(Cc + k)
+    N, H, W = 2, 19, 13
+    x = torch.randn(N, Cc, H, W, generator=g).to(dtype).float()
+    dy = torch.randn(N, Cc, H, W, generator=g).to(dtype).float()
+    w = torch.zeros(Cc, 1, k, k, requires_grad=True)
+    b = torch.zeros(Cc, requires_grad=True)
+    F.conv2d(x, w, b, 1, k // 2, groups=Cc).backward(dy)
+    xd, dyd = nhwc(x, dtype), nhwc(dy, dtype)
+    dw, db = torch.empty(k * k, Cc, device=DEV), torch.empty(Cc, device=DEV)
+    nb = lib.mtbt_dwconv_wgrad_workspace_bytes(N, H, W, Cc, k)
+    ws = torch.empty(nb // 4, device=DEV)
+    L.check(lib.mtbt_dwconv_wgrad_bias(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, W, Cc, k, CODE[dtype], 0, ws.data_ptr(), nb, S()), "dw wgrad")
+    torch.cuda.synchronize()
+    close(dw, w.grad.view(Cc, k * k).t(), 3e-5, "dW")
+    close(db, b.grad, 3e-5, "dbias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc", [96, 384, 768])
+def test_layernorm_backward_with_parameter_gradients(dtype, Cc):
+    lib = L.load()
+    torch.manual_seed(Cc)
+    P = 1000                                         # not a multiple of a wave's pixel run: dead pixels inside live waves
+    x = (torch.randn(P, Cc) * 1.3 + 0.2).to(dtype).float().requires_grad_()
+    gam = (torch.rand(Cc) + 0.5).requires_grad_()
+    bet = torch.zeros(Cc, requires_grad=True)
+    dy = torch.randn(P, Cc).to(dtype).float()
+    F.layer_norm(x, (Cc,), gam, bet, 1e-6).backward(dy)
+    prev = (torch.randn(P, Cc) * 0.01).to(dtype)
+    dx = prev.clone().to(DEV)
+    dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    nb = lib.mtbt_layernorm_backward_params_workspace_bytes(P, Cc)
+    ws = torch.empty(nb // 4, device=DEV)
+    xd, dyd, gd = x.detach().to(DEV, dtype), dy.to(DEV, dtype), gam.detach().to(DEV)
+    L.check(lib.mtbt_layernorm_backward_params_nhwc(xd.data_ptr(), dyd.data_ptr(), gd.data_ptr(), 1e-6, dx.data_ptr(), P, Cc, CODE[dtype], 1, dg.data_ptr(),
+                                                    db.data_ptr(), 0, ws.data_ptr(), nb, S()), "ln bwd params")
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    close(dx.float().cpu() - prev.float(), x.grad, tol, "dx")
+    close(dg, gam.grad, tol, "dgamma")
+    close(db, bet.grad, tol, "dbeta")
