@@ -110,6 +110,11 @@ def _region(a):
     """Dependency-tracking key of an activation view (or a plain tensor): (storage address, channel lo, hi, row pitch).
     A channel slice of a wider buffer (ld > C) is tracked by its channel range; everything else as the whole buffer."""
     if isinstance(a, torch.Tensor):
+        # a contiguous VIEW into a larger storage (a parameter-gradient slot of a flat bucket): tracked by its element range, so that
+        # writers of different slots of one bucket stay independent; everything else as the whole storage
+        if a.is_contiguous() and a.numel() * a.element_size() < a.untyped_storage().nbytes():
+            off = a.storage_offset()
+            return (a.untyped_storage().data_ptr(), off, off + a.numel(), -1)
         return (a.untyped_storage().data_ptr(), 0, 1 << 30, 0)
     key = a.buf.untyped_storage().data_ptr()
     if a.ld != a.C:
@@ -380,7 +385,7 @@ class Plan:
         flops = 2.0 * x.N * Ho * Wo * K * R * S * x.C
         byts = (x.N * x.H * x.W * x.C + K * R * S * x.C) * ESIZE[x.code] + x.N * Ho * Wo * K * ESIZE[y.code]
         self.launches.append(Launch(self.lib.mtbt_conv2d_nhwc, (C.byref(a),), name, (a, x.buf, w, y.buf, scale, shift, res), flops, byts))
-        self._io([x, res], [y])
+        self._io([x, res, w, scale, shift], [y])     # (weights / affine vectors too: a training plan rewrites them at its head)
         return a
 
     def stem(self, x_nchw: torch.Tensor, w, b, lnw, lnb, eps, y: Act, name="stem"):
@@ -401,7 +406,7 @@ class Plan:
         n = x.N * x.H * x.W * x.C
         self.launches.append(Launch(self.lib.mtbt_dwconv_nhwc, args, name, (x.buf, w, bias, lnw, lnb, scale, shift, y.buf),
                                     2.0 * n * ksize * ksize, 2.0 * n * ESIZE[x.code]))
-        self._io([x], [y])
+        self._io([x, w], [y])
 
     def layernorm(self, x: Act, w, b, eps, y: Act, name="layernorm"):
         assert x.dense and y.dense

@@ -49,18 +49,62 @@ def _dense_vec(p: torch.Tensor, what: str) -> torch.Tensor:
     return p
 
 
-class TPlan(Plan):
-    """engine.Plan plus the training-step op builders (all sequential: one shared workspace)."""
+class WsPool:
+    """Scratch buffers of the reduction kernels, handed out round-robin: launches that got DIFFERENT buffers are independent for the lane
+    scheduler (one shared buffer would serialise every weight gradient, channel sum and BatchNorm of the step); stream order plus the
+    recorded write regions keep the reuse of one buffer safe."""
+    SMALL, N_SMALL, N_BIG = 32 << 20, 6, 2
 
-    def __init__(self, device, ws: torch.Tensor):
+    def __init__(self, device):
+        self.device = device
+        self.small: List[torch.Tensor] = []
+        self.big: List[torch.Tensor] = []
+        self.i_small = self.i_big = 0
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if nbytes <= self.SMALL:
+            if len(self.small) < self.N_SMALL:
+                self.small.append(torch.empty(self.SMALL // 4, dtype=torch.float32, device=self.device))
+            self.i_small = (self.i_small + 1) % len(self.small)
+            return self.small[self.i_small]
+        if nbytes > WS_BYTES:
+            raise RuntimeError(f"training workspace too small: {nbytes} > {WS_BYTES} bytes (raise train.WS_BYTES)")
+        if len(self.big) < self.N_BIG:
+            self.big.append(torch.empty(WS_BYTES // 4, dtype=torch.float32, device=self.device))
+        self.i_big = (self.i_big + 1) % len(self.big)
+        return self.big[self.i_big]
+
+
+class TPlan(Plan):
+    """engine.Plan plus the training-step op builders.  Every builder records what its launch reads and writes, so the plan can be
+    issued on one stream or spread over the engine's lanes."""
+
+    def __init__(self, device, ws: WsPool):
         super().__init__(device)
-        self.ws = ws
+        self.wsp = ws
+        self.cur_ws: Optional[torch.Tensor] = None
+        self._late: List[torch.Tensor] = []
         self.pool.reuse = False
 
     def _ws(self, nbytes: int) -> int:
-        if nbytes > self.ws.numel() * 4:
-            raise RuntimeError(f"training workspace too small: {nbytes} > {self.ws.numel() * 4} bytes (raise train.WS_BYTES)")
-        return self.ws.data_ptr()
+        """Scratch for the launch being built: returns its pointer; `self.cur_ws` (the tensor) goes into that launch's write set."""
+        self.cur_ws = self.wsp.get(nbytes)
+        return self.cur_ws.data_ptr()
+
+    def release(self, a: Act):
+        """Return a temporary to the pool -- a few releases LATER: handed out again at once, the buffer would tie its next writer (on the
+        main chain) to its last reader (a weight gradient that could run beside the chain on a side lane)."""
+        self.release_buf(a.buf)
+
+    def release_buf(self, t: torch.Tensor):
+        self._late.append(t)
+        if len(self._late) > 8:
+            self.pool.put(self._late.pop(0))
+
+    def est(self, nbytes: float = 0.0, flops: float = 0.0):
+        """Cost estimate of the launch just appended (the lane scheduler keeps machine-filling launches on lane 0)."""
+        l = self.launches[-1]
+        l.bytes, l.flops = max(l.bytes, nbytes), max(l.flops, flops)
 
     def conv2(self, x: Act, w, y: Act, *, y2: Optional[Act] = None, **kw):
         a = self.conv(x, w, y, **kw)
@@ -81,7 +125,8 @@ class TPlan(Plan):
         g, b = _dense_vec(bn.weight, name + ".weight"), _dense_vec(bn.bias, name + ".bias")
         args = (x.ptr, y.ptr, y.ld, g.data_ptr(), b.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C.c_float(bn.momentum),
                 C.c_float(bn.eps), act, pixels, x.C, x.code, int(use_running), stats.data_ptr(), self._ws(nbytes), nbytes)
-        self.raw(self.lib.mtbt_bn_forward_nhwc, args, name, keep=(x.buf, y.buf, stats, bn), reads=[x], writes=[y, stats, self.ws])
+        self.raw(self.lib.mtbt_bn_forward_nhwc, args, name, keep=(x.buf, y.buf, stats, bn), reads=[x], writes=[y, stats, self.cur_ws])
+        self.est(3.0 * pixels * x.C * ESIZE[x.code])
 
     def bn_backward(self, dy: Act, x: Act, stats, bn, act, use_running: bool, dx: Act, dgamma, dbeta, name):
         assert x.dense and dx.dense and dy.C == x.C and dy.bs == dy.H * dy.W * dy.ld and dy.code == x.code == dx.code
@@ -90,7 +135,8 @@ class TPlan(Plan):
         args = (dy.ptr, dy.ld, x.ptr, stats.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), C.c_float(bn.eps), act, int(use_running), dx.ptr,
                 _ptr(dgamma), _ptr(dbeta), 0, pixels, x.C, x.code, self._ws(nbytes), nbytes)
         self.raw(self.lib.mtbt_bn_backward_nhwc, args, name, keep=(dy.buf, x.buf, stats, dx.buf, dgamma, dbeta, bn), reads=[dy, x, stats],
-                 writes=[dx, dgamma, dbeta, self.ws])
+                 writes=[dx, dgamma, dbeta, self.cur_ws])
+        self.est(5.0 * pixels * x.C * ESIZE[x.code])
 
     def wgrad(self, x: Act, dy: Act, out: torch.Tensor, *, R, S, pad, stride=1, dbias: Optional[torch.Tensor] = None, name="wgrad"):
         """dW (and, with `dbias`, sum_p dy -- the bias gradient, from the same launch)."""
@@ -100,11 +146,11 @@ class TPlan(Plan):
         nbytes = self.lib.mtbt_conv_wgrad_workspace_bytes(x.N, max(x.H, dy.H), max(x.W, dy.W), x.C, dy.C, R, S)
         tail = (x.N, x.H, x.W, x.C, dy.C, R, S, pad, stride, x.batch_stride, x.ld, dy.batch_stride, dy.ld, x.code, 0, self._ws(nbytes), nbytes)
         if dbias is None:
-            self.raw(self.lib.mtbt_conv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.ws])
+            self.raw(self.lib.mtbt_conv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.cur_ws])
         else:
             self.raw(self.lib.mtbt_conv_wgrad_bias, (x.ptr, dy.ptr, out.data_ptr(), dbias.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out, dbias),
-                     reads=[x, dy], writes=[out, dbias, self.ws])
-        self.launches[-1].flops = 2.0 * dy.N * dy.H * dy.W * dy.C * R * S * x.C
+                     reads=[x, dy], writes=[out, dbias, self.cur_ws])
+        self.est(1.0 * dy.N * dy.H * dy.W * (dy.C + x.C) * ESIZE[x.code], 2.0 * dy.N * dy.H * dy.W * dy.C * R * S * x.C)
 
     def channel_sum(self, x: Act, out: torch.Tensor, times: Optional[Act] = None, name="channel_sum"):
         assert x.bs == x.H * x.W * x.ld and (times is None or (times.bs == times.H * times.W * times.ld and times.code == x.code))
@@ -113,7 +159,8 @@ class TPlan(Plan):
         args = (x.ptr, times.ptr if times is not None else None, P, x.C, x.ld, times.ld if times is not None else 0, x.code, out.data_ptr(), 0,
                 self._ws(nbytes), nbytes)
         self.raw(self.lib.mtbt_channel_sum, args, name, keep=(x.buf, times.buf if times is not None else None, out), reads=[x, times],
-                 writes=[out, self.ws])
+                 writes=[out, self.cur_ws])
+        self.est(1.0 * P * x.C * ESIZE[x.code] * (2 if times is not None else 1))
 
     def ln_backward_params(self, x: Act, dy: Act, gamma: torch.Tensor, eps, dx: Act, accumulate: bool, dgamma: torch.Tensor, dbeta: torch.Tensor, name):
         """LayerNorm backward with d gamma / d beta from the same pass (no xhat tensor, no channel-sum passes)."""
@@ -123,7 +170,8 @@ class TPlan(Plan):
         args = (x.ptr, dy.ptr, gamma.data_ptr(), C.c_float(eps), dx.ptr, P, x.C, x.code, int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), 0,
                 self._ws(nbytes), nbytes)
         self.raw(self.lib.mtbt_layernorm_backward_params_nhwc, args, name, keep=(x.buf, dy.buf, gamma, dx.buf, dgamma, dbeta),
-                 reads=[x, dy] + ([dx] if accumulate else []), writes=[dx, dgamma, dbeta, self.ws])
+                 reads=[x, dy] + ([dx] if accumulate else []), writes=[dx, dgamma, dbeta, self.cur_ws])
+        self.est(3.0 * P * x.C * ESIZE[x.code])
 
     def dwconv_t(self, x: Act, w, y: Act, ksize, *, bias=None, lnw=None, lnb=None, eps=0.0, scale=None, shift=None, act=L.ACT_NONE,
                  raw: Optional[Act] = None, res: Optional[Act] = None, name="dwconv"):
@@ -131,7 +179,7 @@ class TPlan(Plan):
         args = (x.ptr, w.data_ptr(), _ptr(bias), _ptr(lnw), _ptr(lnb), C.c_float(eps), _ptr(scale), _ptr(shift), act, y.ptr,
                 raw.ptr if raw is not None else None, res.ptr if res is not None else None, x.N, x.H, x.W, x.C, ksize, x.code)
         self.raw(self.lib.mtbt_dwconv_nhwc_train, args, name, keep=(x.buf, w, bias, lnw, lnb, scale, shift, y.buf, raw and raw.buf, res and res.buf),
-                 reads=[x, res], writes=[y, raw])
+                 reads=[x, res, w, bias, lnw, lnb, scale, shift], writes=[y, raw])
         n = x.N * x.H * x.W * x.C
         self.launches[-1].flops, self.launches[-1].bytes = 2.0 * n * ksize * ksize, 2.0 * n * ESIZE[x.code]
 
@@ -140,10 +188,11 @@ class TPlan(Plan):
         nbytes = self.lib.mtbt_dwconv_wgrad_workspace_bytes(x.N, x.H, x.W, x.C, ksize)
         tail = (x.N, x.H, x.W, x.C, ksize, x.code, 0, self._ws(nbytes), nbytes)
         if dbias is None:
-            self.raw(self.lib.mtbt_dwconv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.ws])
+            self.raw(self.lib.mtbt_dwconv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.cur_ws])
         else:
             self.raw(self.lib.mtbt_dwconv_wgrad_bias, (x.ptr, dy.ptr, out.data_ptr(), dbias.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out, dbias),
-                     reads=[x, dy], writes=[out, dbias, self.ws])
+                     reads=[x, dy], writes=[out, dbias, self.cur_ws])
+        self.est(6.0 * x.N * x.H * x.W * x.C * ESIZE[x.code])
 
     def copy_strided(self, src_ptr, src_code, sbs, sld, dst: Act, N, pixels, Cc, Cpad, keep, name):
         args = (src_ptr, src_code, sbs, sld, dst.ptr, dst.code, dst.bs, dst.ld, N, pixels, Cc, Cpad)
@@ -222,7 +271,7 @@ class TrainPlan:
         self.tail_prefixes = tuple(tail_prefixes)
         self.lib = L.load()
         self.shape = tuple(shape)
-        self.ws = torch.empty(WS_BYTES // 4, dtype=torch.float32, device=device)
+        self.ws = WsPool(device)
         self.fwd = TPlan(device, self.ws)
         self.tape: List = []
         self.prep: List[dict] = []
@@ -375,7 +424,7 @@ class TrainPlan:
             return
         gb.left -= a.C
         if gb.left <= 0:
-            self.bwd.pool.put(gb.t)
+            self.bwd.release_buf(gb.t)
             del self.gmap[self._gkey(a)]
 
     def alias_grad(self, dst_fwd: Act, src_fwd: Act):
@@ -545,7 +594,8 @@ class TrainPlan:
             nbytes = self.lib.mtbt_stem_wgrad_workspace_bytes(a.C)
             dW = self.pg(st0.weight)
             self.bwd.raw(self.lib.mtbt_stem_wgrad, (self.x.data_ptr(), d_raw.ptr, dW.data_ptr(), N, H, W, a.C, T, 0, self.bwd._ws(nbytes), nbytes),
-                         "stem.wgrad", keep=(self.x, d_raw.buf, dW), reads=[self.x, d_raw], writes=[dW, self.ws])
+                         "stem.wgrad", keep=(self.x, d_raw.buf, dW), reads=[self.x, d_raw], writes=[dW, self.bwd.cur_ws])
+            self.bwd.est(1.0 * N * 3 * H * W * 4)
             self.bwd.release(d_raw)
         self.tape.append(stem_bwd)
 
@@ -693,7 +743,8 @@ class TrainPlan:
                         args = (ds.ptr, xin.ptr, mode, wn.data_ptr() + 4 * (col * n + i), gx.ptr, int(acc), dwn.data_ptr() + 4 * (col * n + i), 0,
                                 s.N, s.H, s.W, s.C, self.code, self.bwd._ws(nbytes), nbytes)
                         self.bwd.raw(self.lib.mtbt_bifpn_fuse_backward, args, f"{nm}.{tag}.fuse.bwd{i}", keep=(ds.buf, xin.buf, wn, gx.buf, dwn),
-                                     reads=[ds, xin, wn] + ([gx] if acc else []), writes=[gx, dwn, self.ws])
+                                     reads=[ds, xin, wn] + ([gx] if acc else []), writes=[gx, dwn, self.bwd.cur_ws])
+                        self.bwd.est(2.0 * s.N * s.H * s.W * s.C * ESIZE[self.code])
                     self.done(s)
                 self.tape.append(bwd)
                 dd = self.dw_pointwise(s, conv, f"{nm}.{tag}_conv")
@@ -886,9 +937,18 @@ class TrainPlan:
         if [p.data_ptr() for p in self.m.parameters()] != self.param_ptrs:
             raise RuntimeError("parameter storage moved since the training plan was lowered (re-lower: model._train_plans.clear())")
 
+    def issue(self, plan: TPlan, marks=None):
+        """Spread a plan over the engine's lanes (independent launches -- weight gradients beside the input-gradient chain, the small
+        pyramid levels side by side; bit-identical to single-stream execution: no atomics anywhere, tests/test_gpu_train.py), or, with
+        MTBT_TRAIN_LANES=0, issue it on the current stream.  Measured at batch 32: 80.0 -> 79.3 ms per step."""
+        import os
+        if os.environ.get("MTBT_TRAIN_LANES", "1") == "1":
+            return plan.run(marks=marks)
+        return plan.run(stream=torch.cuda.current_stream(self.device).cuda_stream, marks=marks)
+
     def run_forward(self, x: torch.Tensor):
         self.x.copy_(x)
-        self.fwd.run(stream=torch.cuda.current_stream(self.device).cuda_stream)
+        self.issue(self.fwd)
         self.generation += 1
         if self.train_bns:
             torch._foreach_add_([bn.num_batches_tracked for bn in self.train_bns if bn.num_batches_tracked is not None], 1)
@@ -897,7 +957,7 @@ class TrainPlan:
 
     def run_backward(self, active: Sequence[str]):
         plan = self.backward_plan(active)
-        plan.run(stream=torch.cuda.current_stream(self.device).cuda_stream)
+        self.issue(plan)
         return plan
 
 

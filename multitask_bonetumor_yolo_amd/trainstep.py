@@ -143,17 +143,17 @@ class TrainStep:
     def _backward_and_exchange(self):
         main = torch.cuda.current_stream(self.dev)
         if self.world == 1:
-            self.bwd.run(stream=main.cuda_stream)
+            self.tp.issue(self.bwd)
             return
         live = list(range(self.n_skip, len(self.grads.buckets)))
         if self.comm is None:
-            self.bwd.run(stream=main.cuda_stream)
+            self.tp.issue(self.bwd)
             for b in live:
                 self._mean_over_ranks(self.grads.buckets[b])
             self._reduce_projector()
             return
         marks = {str(b): [self.ready[b]] for b in live if self.ready[b] >= 0}
-        events = self.bwd.run(stream=main.cuda_stream, marks=marks)
+        events = self.tp.issue(self.bwd, marks=marks)
         # buckets complete in bucket order (reverse registration = backward order); each collective waits only for ITS last producer
         with torch.cuda.stream(self.comm):
             for b in sorted(live, key=lambda k: self.ready[k]):

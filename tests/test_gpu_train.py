@@ -238,6 +238,7 @@ def test_two_rank_step_equals_averaged_gradients(tmp_path):
                         "--master-port", "29533", os.path.join(root, "tools", "ddp_worker.py"), out], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = torch.load(out, weights_only=True)
+    assert got["side_stream_all_reduce"] is True or str(got["side_stream_all_reduce"]).startswith("skipped"), got["side_stream_all_reduce"]
     # ---- the same two steps in one process: per-shard gradients, averaged by hand ----
     S, per = 128, 2
     model = W.build_model(torch.device(DEV))
@@ -262,3 +263,31 @@ def test_two_rank_step_equals_averaged_gradients(tmp_path):
         err = (a - b.cpu()).abs().max().item()
         assert err <= 1e-5 * (b.abs().max().item() + 1e-6) + 1e-7, f"parameter bucket {i}: {err}"
     assert (got["proj"] - ts.pj.cpu()).abs().max().item() <= 1e-5
+
+
+def test_training_plans_on_lanes_are_bit_identical(monkeypatch):
+    """MTBT_TRAIN_LANES=1 spreads the forward / backward launches over the engine's HIP streams following the recorded read / write regions
+    (per-launch scratch buffers, parameter-gradient slots tracked by element range).  No atomics anywhere, so every gradient must equal
+    the single-stream result BIT FOR BIT -- a missing dependency shows up here as a difference."""
+    from multitask_bonetumor_yolo_amd.trainstep import TrainStep
+    ora, hip = build("main", seed=12)
+    hip.set_compute_dtype(torch.bfloat16)
+    S, B = 256, 4
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, 3, S, S, generator=g).to(DEV)
+    gt_boxes = torch.tensor([[b, b % 2, 0.4 + 0.05 * b, 0.5, 0.3, 0.35] for b in range(B)], dtype=torch.float32).to(DEV)
+    gt_masks = torch.zeros(B, 1, S, S, device=DEV)
+    gt_masks[:, 0, 60:140, 50:170] = 1
+    gt_cls = torch.tensor([0, 1, 1, 0]).to(DEV)
+    ts = TrainStep(hip, (B, 3, S, S), optimizer="sgd", lr=0.0, iou_match_thresh=0.05)     # lr 0: the weights stay put between the runs
+    monkeypatch.setenv("MTBT_TRAIN_LANES", "0")
+    ts.forward_backward(x, gt_boxes, gt_masks, gt_cls)
+    torch.cuda.synchronize()
+    ref = [b.clone() for b in ts.grads.buckets]
+    monkeypatch.setenv("MTBT_TRAIN_LANES", "1")
+    monkeypatch.setenv("MTBT_LANES", "4")
+    for _ in range(6):
+        ts.forward_backward(x, gt_boxes, gt_masks, gt_cls)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(ref, ts.grads.buckets)):
+            assert torch.equal(a, b), f"gradient bucket {i} differs between single-stream and lane execution"

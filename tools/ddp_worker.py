@@ -57,7 +57,26 @@ if __name__ == "__main__":
         x, bx, mk, cl = (t.to(dev) for t in shard(batch, rank, per))
         losses.append(ts.step(x, bx, mk, cl).cpu())
     torch.cuda.synchronize()
+    # dist_train.FlatBuckets.all_reduce_mean on a SIDE stream: the buckets are filled on the compute stream behind a long
+    # kernel; the collective must wait for that stream (captured OUTSIDE the side-stream context), not start on stale data
+    from multitask_bonetumor_yolo_amd.dist_train import FlatBuckets
+    fb = FlatBuckets([("a", (1 << 20,)), ("b", (3, 1 << 18))], dev, bucket_bytes=2 << 20)
+    side = torch.cuda.Stream(device=dev)
+    big = torch.randn(4096, 4096, device=dev)
+    for _ in range(6):
+        big = big @ big * 1e-4                      # ~10 ms of work in front of the fill
+    fb.views["a"].copy_(big.flatten()[: 1 << 20] * 0 + float(rank + 1))
+    fb.views["b"].fill_(float(10 * (rank + 1)))
+    try:
+        works = fb.all_reduce_mean(stream=side)
+        for w in works:
+            w.wait()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        side_ok = bool((fb.views["a"] == (world + 1) / 2).all() and (fb.views["b"] == 10 * (world + 1) / 2).all())
+    except RuntimeError as e:                         # a gloo build without device-tensor collectives
+        side_ok = f"skipped: {e}"[:120]
     if rank == 0:
-        torch.save({"buckets": [b.cpu() for b in ts.params.buckets], "proj": ts.pj.cpu(), "losses": losses, "host_staged": ts._host_staged}, out)
+        torch.save({"buckets": [b.cpu() for b in ts.params.buckets], "proj": ts.pj.cpu(), "losses": losses, "host_staged": ts._host_staged, "side_stream_all_reduce": side_ok}, out)
     dist.barrier()
     dist.destroy_process_group()
