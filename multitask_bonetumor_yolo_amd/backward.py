@@ -6,10 +6,12 @@ backward pass.  No new GEMM kernel is needed for any of 
   2 x 2, stride 2    dX = conv_transpose(dY, W): the OUT_CONVT2X2 scatter mode of the same kernel   (ConvNeXt downsample)
   depthwise k x k    the depthwise kernel on dY with the taps flipped                                (mtbt_dwconv_nhwc)
 
-`conv_wgrad` is the weight gradient of the dense convolutions (any stride) (csrc/wgrad.hip: transposed LDS reads feed the MFMA, bf16 in,
-fp32 out, deterministic split reduction).  These are the linear parts only: the activation derivative on the way in and the
-normalisation backward are not built yet.  Everything here appends launches to an `engine.Plan`; weights are re-laid out once by the
-`*_weight` helpers (device tensors, any dtype the kernels take)."""
+`conv_wgrad` is the weight gradient of the dense convolutions (any stride) (csrc/wgrad.hip: transposed LDS reads feed the MFMA, fp32 out,
+deterministic split reduction; 3x3 / stride 1 from an LDS halo tile).  The helpers below are the STAND-ALONE forms of the backward operators
+(one call = one launch, scratch allocated per call) that the kernel tests and probes use; the assembled training step -- the forward
+that keeps what backward needs, the backward launch plan with plan-resident scratch, the autograd boundary -- is `train.py` /
+`trainstep.py` (DESIGN.md section 7).  The plan-building helpers (`conv_dgrad`, `dwconv_dgrad`, ...) append launches to an `engine.Plan`;
+weights are re-laid out once by the `*_weight` helpers (device tensors, any dtype the kernels take)."""
 import ctypes as C
 
 import torch

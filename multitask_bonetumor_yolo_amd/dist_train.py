@@ -7,8 +7,9 @@ enough to reach link bandwidth while leaving several buckets to overlap with the
 gradients (44.8 M parameters) are 8 buckets.  The buckets are filled in REVERSE registration order, the order in which a
 backward pass produces gradients, so bucket 0 can be reduced while earlier layers are still being differentiated.
 
-What is not here yet: the kernels that produce the gradients.  Until then `FlatBuckets` takes
-gradients from any source (the tests use plain tensors)."""
+`FlatBuckets` is also the storage of the training step's parameter / gradient arenas (`train.make_arena`, kernel layouts, a leading
+bucket for parameters the loss never reaches); the step that fills the gradient buckets, all-reduces each one under the rest of the
+backward pass and applies the fused optimiser is `trainstep.TrainStep` (DESIGN.md sections 6-7)."""
 import ctypes as C
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 

@@ -1,7 +1,9 @@
 """Multitask loss value on the GPU: the reference's `MultiTaskLitModel._multitask_loss`
 (`/root/reference/src/running_main_v3.py:232-387`) as three kernel launches (csrc/loss.hip) instead of a per-image Python
 loop with `.item()` synchronisations.  The returned 0-d tensors carry no autograd history; `with_grads=True` additionally
-returns the gradient of the total with respect to the head outputs (the rest of the backward pass is not built yet).
+returns the gradient of the total with respect to the head outputs -- what `trainstep.TrainStep` feeds the backward launch plan
+(`grad_out` writes it straight into that plan's input buffers).  (Under the drop-in autograd route the trainer's own torch loss is
+used instead, on the tensors `forward(x, "train")` returns.)
 
 No host synchronisation: the ground-truth boxes are grouped by image with device-side tensor ops, the positive count and
 the mean matched IoU come back as tensors (the reference returns Python floats, `:385`)."""

@@ -20,6 +20,7 @@ extern "C" int dw_variant(int id, const void* x, const void* w, const float* bia
       V(6, 2, 16, 1, 8, 2, true)
       V(7, 4, 8, 1, 4, 4, false)     // XB = 4: 4 waves per 4x8 tile, fewer accumulators
       V(8, 4, 16, 1, 4, 3, false)
+      case 9: return launch_dw<bf16_t, 7, false, 4, 16, 1, 8, 2, true>(x, w, nullptr, nullptr, nullptr, 0.f, lnw, lnb, 0, y, nullptr, nullptr, N, H, W, C, s);   // no LayerNorm: y = conv * lnw + lnb
     }
   } else if (nch == 2) {
     switch (id) {
@@ -30,6 +31,7 @@ extern "C" int dw_variant(int id, const void* x, const void* w, const float* bia
       V(5, 2, 16, 2, 8, 4, false)
       V(7, 4, 8, 2, 4, 4, false)
       V(8, 4, 16, 2, 4, 3, false)
+      case 9: return launch_dw<bf16_t, 7, false, 4, 16, 2, 8, 2, false>(x, w, nullptr, nullptr, nullptr, 0.f, lnw, lnb, 0, y, nullptr, nullptr, N, H, W, C, s);
     }
   }
   return -100;
