@@ -380,8 +380,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const T* __re
       }
     }
   }
-  // fold the wave's 64/LP pixel groups (same channels in lanes gl, gl + LP, ...) and write one row per wave
-  float* row = partial + wave_id * 2 * C;
+  // fold the wave's 64/LP pixel groups (same channels in lanes gl, gl + LP, ...), then the workgroup's four waves through LDS in
+  // wave order, and write ONE row per workgroup (the second level reads a quarter of the rows)
+  extern __shared__ __attribute__((aligned(16))) float lnb_red[];   // [4][2 * C]
+  float* row = lnb_red + (threadIdx.x >> 6) * 2 * C;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int ch = gl + i * LP;
@@ -393,6 +395,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const T* __re
       if (lane < LP && ch < CH8) { row[ch * 8 + e] = a; row[C + ch * 8 + e] = b; }
     }
   }
+  __syncthreads();
+  float* out = partial + (long)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) out[c] = ((lnb_red[c] + lnb_red[2 * C + c]) + lnb_red[4 * C + c]) + lnb_red[6 * C + c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,7 +691,7 @@ extern "C" int64_t mtbt_layernorm_backward_params_workspace_bytes(int64_t pixels
   const int LP = CH8 <= 16 ? 16 : (CH8 <= 32 ? 32 : 64);
   const int64_t per = (int64_t)lnb_iters(pixels, 64 / LP) * (64 / LP);
   const int64_t waves = (pixels + per - 1) / per;
-  return ((waves + 3) / 4 * 4) * 2 * (int64_t)C * (int64_t)sizeof(float);
+  return ((waves + 3) / 4) * 2 * (int64_t)C * (int64_t)sizeof(float);
 }
 
 // LayerNorm backward over the channels of every pixel plus the parameter gradients in the same pass:
@@ -705,9 +710,13 @@ extern "C" int mtbt_layernorm_backward_params_nhwc(const void* x, const void* dy
   const long blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
   float* partial = reinterpret_cast<float*>(workspace);
-#define LNP_LAUNCH(T, MAXV, LPV) \
-  hipLaunchKernelGGL((layernorm_bwd_params_kernel<T, MAXV, LPV>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, w, eps, (T*)dx, \
-                     (long)pixels, C, accumulate_dx, partial, iters)
+  const int lds = 4 * 2 * C * (int)sizeof(float);
+#define LNP_LAUNCH(T, MAXV, LPV)                                                                                                          \
+  do {                                                                                                                                    \
+    if (int rc = mtbt_allow_lds(layernorm_bwd_params_kernel<T, MAXV, LPV>, lds)) return rc;                                                \
+    hipLaunchKernelGGL((layernorm_bwd_params_kernel<T, MAXV, LPV>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)x, (const T*)dy, w, eps, \
+                       (T*)dx, (long)pixels, C, accumulate_dx, partial, iters);                                                            \
+  } while (0)
 #define LNP_BY_C(T) \
   do { if (LP == 16) LNP_LAUNCH(T, 1, 16); else if (LP == 32) LNP_LAUNCH(T, 1, 32); else if (CH8 <= 64) LNP_LAUNCH(T, 1, 64); \
        else if (CH8 <= 128) LNP_LAUNCH(T, 2, 64); else LNP_LAUNCH(T, 4, 64); } while (0)
@@ -716,7 +725,7 @@ extern "C" int mtbt_layernorm_backward_params_nhwc(const void* x, const void* dy
   else return MTBT_EINVAL;
 #undef LNP_BY_C
 #undef LNP_LAUNCH
-  const int rows = (int)(blocks * 4);     // (waves past the last pixel write zero rows)
+  const int rows = (int)blocks;           // (waves past the last pixel contribute zeros)
   hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, rows, 2 * C, 0, C, dbeta, accumulate_params);
   hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, rows, 2 * C, C, C, dgamma, accumulate_params);
   MTBT_LAUNCH_CHECK();

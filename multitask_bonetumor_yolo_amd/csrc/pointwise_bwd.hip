@@ -80,7 +80,7 @@ template <> __device__ __forceinline__ f32p ld_pair<bf16_t>(const char* p) {
 
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
-                                                            float* __restrict__ partial /* [slots * 4][(KS*KS + 1) * C]: taps, then sum_p dy */) {
+                                                            float* __restrict__ partial /* [slots][(KS*KS + 1) * C]: taps, then sum_p dy */) {
   constexpr int PAD = KS / 2, TS = 8, IW = TS + KS - 1, ES = (int)sizeof(T), PIXB = 128 * ES, EPC = 16 / ES, PARTS = PIXB / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xt = smem;                       // [IW*IW][128] T
@@ -136,13 +136,36 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
       }
     }
   }
-  // partial row (slot, wave): the workgroups of one slot (one per chunk) write disjoint column ranges of the same rows, so every row
-  // is complete without any zero fill
-  float* dst = partial + ((long)slot * 4 + wave) * (KS * KS + 1) * C;
-  if (active) {
+  // fold the four waves of the workgroup through LDS (waves 2, 3 -> 0, 1, then 1 -> 0; a fixed order) so that ONE partial row per
+  // workgroup goes out: the second level reads a quarter of the rows
+  f32p* red = reinterpret_cast<f32p*>(smem);             // [2][KS*KS + 1][64] pairs <= 51 KiB, inside the tile region
+  constexpr int KK1 = KS * KS + 1;
+  __syncthreads();                                        // the last tile's readers are done
+  if (wave >= 2) {
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) *reinterpret_cast<f32p*>(dst + (long)t * C + cb + lane * 2) = acc[t];
-    *reinterpret_cast<f32p*>(dst + (long)KS * KS * C + cb + lane * 2) = accb;
+    for (int t = 0; t < KS * KS; ++t) red[((wave - 2) * KK1 + t) * 64 + lane] = acc[t];
+    red[((wave - 2) * KK1 + KS * KS) * 64 + lane] = accb;
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) acc[t] += red[(wave * KK1 + t) * 64 + lane];
+    accb += red[(wave * KK1 + KS * KS) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) red[t * 64 + lane] = acc[t];
+    red[KS * KS * 64 + lane] = accb;
+  }
+  __syncthreads();
+  // partial row `slot`: the workgroups of one slot (one per chunk) write disjoint column ranges of the same row, so every row is
+  // complete without any zero fill
+  float* dst = partial + (long)slot * KK1 * C;
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) *reinterpret_cast<f32p*>(dst + (long)t * C + cb + lane * 2) = acc[t] + red[t * 64 + lane];
+    *reinterpret_cast<f32p*>(dst + (long)KS * KS * C + cb + lane * 2) = accb + red[KS * KS * 64 + lane];
   }
 }
 
@@ -223,7 +246,7 @@ static int dw_wgrad_blocks(int N, int H, int W, int C) {
 
 extern "C" int64_t mtbt_dwconv_wgrad_workspace_bytes(int N, int H, int W, int C, int ksize) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || ksize <= 0) return 0;
-  return (int64_t)(dw_wgrad_blocks(N, H, W, C) / ((C + 127) / 128)) * 4 * (ksize * ksize + 1) * C * (int64_t)sizeof(float);
+  return (int64_t)(dw_wgrad_blocks(N, H, W, C) / ((C + 127) / 128)) * (ksize * ksize + 1) * C * (int64_t)sizeof(float);
 }
 
 static int dw_wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int ksize, int dtype, int accumulate,
@@ -248,7 +271,7 @@ static int dw_wgrad_entry(const void* x, const void* dy, float* dw, float* dbias
   if (dtype == MTBT_BF16) { if (ksize == 7) DWT(bf16_t, 7); else DWT(bf16_t, 3); }
   else { if (ksize == 7) DWT(float, 7); else DWT(float, 3); }
 #undef DWT
-  const int rows = (blocks / chunks) * 4, pitch = n + C;
+  const int rows = blocks / chunks, pitch = n + C;
   hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, partial, rows, pitch, 0, n, dw, accumulate);
   if (dbias) hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, rows, pitch, n, C, dbias, accumulate);
   MTBT_LAUNCH_CHECK();

@@ -314,18 +314,28 @@ __global__ __launch_bounds__(256) void scale_grad_rows(const float* __restrict__
   }
 }
 
+// workgroup = 64 columns x 4 row groups (lane = column: 256-byte row segments); the row groups are added in a fixed order through LDS
 __global__ __launch_bounds__(256) void scale_grad_cols(const float* __restrict__ G, const float* __restrict__ W, const float* __restrict__ vec,
                                                        float* __restrict__ dW, float* __restrict__ dvec, int K, int C, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float v = vec[c];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float dot = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const float gv = G[(long)k * C + c];
-    dot += gv * W[(long)k * C + c];
-    dW[(long)k * C + c] = accumulate ? dW[(long)k * C + c] + gv * v : gv * v;
+  if (c < C) {
+    const float v = vec[c];
+#pragma unroll 4
+    for (int k = rg; k < K; k += 4) {
+      const float gv = G[(long)k * C + c];
+      dot += gv * W[(long)k * C + c];
+      dW[(long)k * C + c] = accumulate ? dW[(long)k * C + c] + gv * v : gv * v;
+    }
   }
-  dvec[c] = accumulate ? dvec[c] + dot : dot;
+  red[rg][lane] = dot;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    dvec[c] = accumulate ? dvec[c] + t : t;
+  }
 }
 
 template <typename T>
@@ -450,7 +460,7 @@ extern "C" int mtbt_scale_grad(int mode, const float* G, const float* W, const f
     if ((bias || dbias) && !s) return MTBT_EINVAL;
     hipLaunchKernelGGL(scale_grad_rows, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, G, W, vec, bias, s, dW, dvec, dbias, K, C, accumulate);
   } else {
-    hipLaunchKernelGGL(scale_grad_cols, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, G, W, vec, dW, dvec, K, C, accumulate);
+    hipLaunchKernelGGL(scale_grad_cols, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, G, W, vec, dW, dvec, K, C, accumulate);
   }
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;

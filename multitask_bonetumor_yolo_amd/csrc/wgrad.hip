@@ -153,8 +153,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float s = accumulate ? dw[i] : 0.f;
+#pragma unroll 4
   for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];
   dw[i] = s;
+}
+
+// small tensors with many slices (a serial walk of the slices by n / 256 workgroups is latency-bound): workgroup = 64 elements x 4 slice
+// groups, added in a fixed order through LDS
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ partial, float* __restrict__ dw, long n, int nsplit, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < n) {
+#pragma unroll 4
+    for (int k = g; k < nsplit; k += 4) s += partial[(long)k * n + i];
+  }
+  red[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+static inline void launch_wgrad_reduce(const float* partial, float* dw, long n, int nsplit, int accumulate, hipStream_t st) {
+  if (nsplit >= 8 && n <= (1L << 20))
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partial, dw, n, nsplit, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, dw, n, nsplit, accumulate);
 }
 
 // ---- 3x3 / stride 1 / pad 1 from an LDS HALO TILE.  The generic kernel above gives every filter tap its own workgroups, so a 3x3 layer
@@ -469,8 +496,8 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
     const long blocks = (long)p.nsplit * R * S * p.ktiles * p.ctiles;
     if (blocks > 0x7fffffffL) return MTBT_EINVAL;
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.partial, dw, n, p.nsplit, accumulate);
-    if (dbias) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, bpartial, dbias, (long)K, p.nsplit, accumulate);
+    launch_wgrad_reduce(p.partial, dw, n, p.nsplit, accumulate, st);
+    if (dbias) launch_wgrad_reduce(bpartial, dbias, (long)K, p.nsplit, accumulate, st);
     MTBT_LAUNCH_CHECK();
     return MTBT_OK;
   }
@@ -492,7 +519,7 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
     const long blocks3 = base * ns;
     if (blocks3 > 0x7fffffffL) return MTBT_EINVAL;
     hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3((unsigned)blocks3), dim3(256), 0, st, q);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q.partial, dw, n, q.nsplit, accumulate);
+    launch_wgrad_reduce(q.partial, dw, n, q.nsplit, accumulate, st);
     MTBT_LAUNCH_CHECK();
     return MTBT_OK;
   }
@@ -509,8 +536,8 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
   if (dbias) hipLaunchKernelGGL(wgrad_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.partial, dw, n, p.nsplit, accumulate);
-  if (dbias) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, bpartial, dbias, (long)K, p.nsplit, accumulate);
+  launch_wgrad_reduce(p.partial, dw, n, p.nsplit, accumulate, st);
+  if (dbias) launch_wgrad_reduce(bpartial, dbias, (long)K, p.nsplit, accumulate, st);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
