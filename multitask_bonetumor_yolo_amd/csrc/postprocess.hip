@@ -108,11 +108,17 @@ __global__ void decode_kernel(const DecodeP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// NMS.  One 256-thread workgroup per image.
-//  1. stable compaction of { a : score[a] > conf_th } (ballot + wave prefix) -> cand list
-//  2. bitonic sort of 64-bit keys (~orderable(score) << 32 | cand index): descending score,
+// NMS.  One 1024-thread workgroup per image.
+//  1. stable compaction of { a : score[a] > conf_th } (each wave owns a contiguous anchor range: count, prefix over the
+//     waves, ballot-prefix writes) -> cand list, plus a 4096-bin histogram of the candidates' scores
+//  2. PRESELECTION: the greedy pass almost never looks past the first few hundred candidates, so only the candidates of
+//     the top histogram bins (the fewest bins holding >= NMS_TARGET of them) are sorted first; every candidate left out has
+//     a strictly smaller score than every one selected, so the sorted selection IS the head of the full order.  If the
+//     greedy pass runs out of selected candidates before top_k boxes are kept, the whole list is sorted and the pass redone
+//     (same result as sorting everything up front, which is what attempt 1 is).
+//  3. bitonic sort of 64-bit keys (~orderable(score) << 32 | cand index): descending score,
 //     ascending candidate index on ties == torch's stable descending sort
-//  3. greedy pass by wave 0, 64 sorted candidates per step: each lane tests its candidate against
+//  4. greedy pass by wave 0, 64 sorted candidates per step: each lane tests its candidate against
 //     every box kept so far, the 64x64 in-chunk dependencies are bitmasks resolved by a scalar scan
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool iou_gt(const float4 bi, const float4 bj, float thr) {
@@ -133,131 +139,223 @@ __device__ __forceinline__ unsigned orderable(float f) {
 }
 
 constexpr int NMS_KEPT_LDS = 1024;  // kept boxes cached in LDS; beyond that they are read back from out_boxes
+constexpr int NMS_NT = 1024, NMS_NW = NMS_NT / 64;
+constexpr int NMS_BINS = 4096;      // score histogram (aliases the kept-box cache: 16 KiB, used before the greedy pass)
+constexpr int NMS_TARGET = 1024;    // preselect at least this many candidates ...
+constexpr int NMS_SEL_MAX = 4096;   // ... and sort everything at once when the top bins hold more than this
 
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ score,
-                                                  const int* __restrict__ label, int A, float conf_th, float iou_th,
-                                                  float clamp_max, int top_k, long long* __restrict__ keep_idx,
-                                                  int* __restrict__ keep_anchor, float* __restrict__ out_boxes,
-                                                  float* __restrict__ out_scores, long long* __restrict__ out_labels,
-                                                  int* __restrict__ counts, int* __restrict__ n_cand, char* __restrict__ ws,
-                                                  long ws_per_image, int P2, int keys_in_lds) {
+// monotone non-decreasing in the score (any float): a candidate in a lower bin has a strictly smaller score
+__device__ __forceinline__ int nms_bin(float v) { return (int)fminf(fmaxf(v * (float)NMS_BINS, 0.f), (float)(NMS_BINS - 1)); }
+
+__global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ score,
+                                                     const int* __restrict__ label, int A, float conf_th, float iou_th,
+                                                     float clamp_max, int top_k, long long* __restrict__ keep_idx,
+                                                     int* __restrict__ keep_anchor, float* __restrict__ out_boxes,
+                                                     float* __restrict__ out_scores, long long* __restrict__ out_labels,
+                                                     int* __restrict__ counts, int* __restrict__ n_cand, char* __restrict__ ws,
+                                                     long ws_per_image, int P2, int keys_in_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int wave_tot[4];
-  __shared__ int s_base;
+  __shared__ int wave_tot[NMS_NW];
+  __shared__ int s_cnt, s_bin, s_sel, s_redo, s_nkept;
+  __shared__ unsigned long long part_supp[NMS_NW * 64], part_dead[NMS_NW];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* wsi = ws + (long)n * ws_per_image;
   float4* sbox = reinterpret_cast<float4*>(wsi);                      // [A] sorted, clamped boxes
   int* cand_anchor = reinterpret_cast<int*>(wsi + (long)A * 16);     // [A]
   unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(wsi + (long)A * 20 + ((16 - ((long)A * 20) % 16) % 16));
   float4* kept_lds = reinterpret_cast<float4*>(smem);                // [NMS_KEPT_LDS]
+  int* hist = reinterpret_cast<int*>(smem);                          // [NMS_BINS] (before the greedy pass)
   unsigned long long* keys = keys_in_lds ? reinterpret_cast<unsigned long long*>(smem + NMS_KEPT_LDS * 16) : gkeys;
   const float* sc = score + (long)n * A;
+  const unsigned long long below = (1ull << lane) - 1ull;
 
-  // ---- 1. compaction (ascending anchor order) ----
-  if (tid == 0) s_base = 0;
+  // ---- 1. compaction (ascending anchor order) + score histogram ----
+  for (int i = tid; i < NMS_BINS; i += NMS_NT) hist[i] = 0;
+  const int per_wave = ((A + NMS_NW - 1) / NMS_NW + 63) / 64 * 64;
+  const int a_lo = wave * per_wave, a_hi = min(A, a_lo + per_wave);
+  int mine = 0;
+  for (int a0 = a_lo; a0 < a_hi; a0 += 64) {
+    const int a = a0 + lane;
+    mine += __popcll(__ballot(a < a_hi && sc[a] > conf_th));
+  }
+  if (lane == 0) wave_tot[wave] = mine;
   __syncthreads();
-  for (int a0 = 0; a0 < A; a0 += 256) {
-    const int a = a0 + tid;
-    const float v = a < A ? sc[a] : 0.f;
-    const bool f = a < A && v > conf_th;
+  int off = 0, M = 0;
+  for (int k = 0; k < NMS_NW; ++k) { if (k < wave) off += wave_tot[k]; M += wave_tot[k]; }
+  for (int a0 = a_lo; a0 < a_hi; a0 += 64) {
+    const int a = a0 + lane;
+    const float v = a < a_hi ? sc[a] : 0.f;
+    const bool f = a < a_hi && v > conf_th;
     const unsigned long long bal = __ballot(f);
-    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wave] = __popcll(bal);
-    __syncthreads();
-    int off = s_base;
-    for (int k = 0; k < wave; ++k) off += wave_tot[k];
     if (f) {
-      const int pos = off + pre;
-      cand_anchor[pos] = a;
-      keys[pos] = ((unsigned long long)(~orderable(v)) << 32) | (unsigned)pos;
+      cand_anchor[off + __popcll(bal & below)] = a;
+      atomicAdd(&hist[nms_bin(v)], 1);
     }
-    __syncthreads();
-    if (tid == 0) s_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
-  }
-  const int M = s_base;
-  int P = 1;
-  while (P < M) P <<= 1;
-  for (int i = M + tid; i < P; i += 256) keys[i] = ~0ull;
-  __syncthreads();
-
-  // ---- 2. bitonic sort ascending over P keys ----
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (P >> 1); t += 256) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long x = keys[lo], y = keys[hi];
-        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
-      }
-      __syncthreads();
-    }
-  }
-
-  // sorted, clamped boxes to workspace
-  const float4* bx = reinterpret_cast<const float4*>(boxes) + (long)n * A;
-  for (int i = tid; i < M; i += 256) {
-    const int ci = (int)(keys[i] & 0xffffffffu);
-    float4 b = bx[cand_anchor[ci]];
-    b.x = fminf(fmaxf(b.x, 0.f), clamp_max); b.y = fminf(fmaxf(b.y, 0.f), clamp_max);
-    b.z = fminf(fmaxf(b.z, 0.f), clamp_max); b.w = fminf(fmaxf(b.w, 0.f), clamp_max);
-    sbox[i] = b;
+    off += __popcll(bal);
   }
   __threadfence_block();
   __syncthreads();
 
-  // ---- 3. greedy (wave 0) ----
+  // ---- 2. the lowest histogram bin of the preselection: the largest b with  #{bin >= b} >= min(M, NMS_TARGET) ----
+  if (tid == 0) { s_bin = 0; s_sel = M; }
+  __syncthreads();
+  if (M > NMS_TARGET) {
+    const int h0 = hist[tid * 4], h1 = hist[tid * 4 + 1], h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+    int x = h0 + h1 + h2 + h3;                                      // -> inclusive suffix sum over the threads
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(x, o, 64); if (lane + o < 64) x += t; }
+    __syncthreads();                                                // (wave_tot is reused)
+    if (lane == 0) wave_tot[wave] = x;
+    __syncthreads();
+    for (int k = wave + 1; k < NMS_NW; ++k) x += wave_tot[k];
+    // S(b) for this thread's four bins and the one above them
+    const int s3 = x - h0 - h1 - h2, s2 = x - h0 - h1, s1 = x - h0, s0 = x, s4 = s3 - h3;
+    const int S[5] = {s0, s1, s2, s3, s4};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (S[i] >= NMS_TARGET && S[i + 1] < NMS_TARGET) { s_bin = tid * 4 + i; s_sel = S[i]; }
+  }
+  __syncthreads();
+  const int sel_bin = s_bin, sel_cnt = s_sel;
+  const bool presel = M > NMS_TARGET && sel_cnt <= NMS_SEL_MAX && sel_cnt < M;
+  __syncthreads();
+
   long long* ki = keep_idx + (long)n * top_k;
   int* ka = keep_anchor + (long)n * top_k;
   float4* ob = reinterpret_cast<float4*>(out_boxes) + (long)n * top_k;
   float* os = out_scores + (long)n * top_k;
   long long* ol = out_labels + (long)n * top_k;
-  if (wave == 0) {
-    int nkept = 0;
-    for (int j0 = 0; j0 < M && nkept < top_k; j0 += 64) {
+  const float4* bx = reinterpret_cast<const float4*>(boxes) + (long)n * A;
+
+  for (int attempt = presel ? 0 : 1; attempt < 2; ++attempt) {
+    // ---- 3. keys of the selection (attempt 0) / of every candidate (attempt 1), bitonic sort ascending ----
+    const int Ms = attempt == 0 ? sel_cnt : M;
+    if (tid == 0) { s_cnt = 0; s_redo = 0; }
+    __syncthreads();
+    for (int p0 = wave * 64; p0 < M; p0 += NMS_NT) {
+      const int pos = p0 + lane;
+      const float v = pos < M ? sc[cand_anchor[pos]] : 0.f;
+      if (attempt == 1) {
+        if (pos < M) keys[pos] = ((unsigned long long)(~orderable(v)) << 32) | (unsigned)pos;
+      } else {
+        const bool f = pos < M && nms_bin(v) >= sel_bin;
+        const unsigned long long bal = __ballot(f);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_cnt, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (f) keys[base + __popcll(bal & below)] = ((unsigned long long)(~orderable(v)) << 32) | (unsigned)pos;   // (any slot: sorted next)
+      }
+    }
+    int P = 1;
+    while (P < Ms) P <<= 1;
+    for (int i = Ms + tid; i < P; i += NMS_NT) keys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (P >> 1); t += NMS_NT) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool up = (lo & k) == 0;
+          const unsigned long long x = keys[lo], y = keys[hi];
+          if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+        }
+        __syncthreads();
+      }
+    }
+
+    // sorted, clamped boxes to workspace
+    for (int i = tid; i < Ms; i += NMS_NT) {
+      const int ci = (int)(keys[i] & 0xffffffffu);
+      float4 b = bx[cand_anchor[ci]];
+      b.x = fminf(fmaxf(b.x, 0.f), clamp_max); b.y = fminf(fmaxf(b.y, 0.f), clamp_max);
+      b.z = fminf(fmaxf(b.z, 0.f), clamp_max); b.w = fminf(fmaxf(b.w, 0.f), clamp_max);
+      sbox[i] = b;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- 4. greedy, 64 sorted candidates per step, all waves: every wave holds the chunk (lane = candidate); wave w tests it
+    //         against kept boxes w, w + 16, ... and against chunk members 4w .. 4w + 3, the partial results meet in LDS and
+    //         wave 0 resolves the in-chunk order (scalar scan over 64-bit masks) and writes the newly kept boxes ----
+    if (tid == 0) s_nkept = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < Ms; j0 += 64) {
+      const int nkept = s_nkept;
+      if (nkept >= top_k) break;                 // (uniform)
       const int j = j0 + lane;
-      const bool have = j < M;
-      const float4 mine = have ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      bool alive = have;
-      for (int k = 0; k < nkept; ++k) {
-        const float4 kb = k < NMS_KEPT_LDS ? kept_lds[k] : ob[k];
-        if (iou_gt(kb, mine, iou_th)) alive = false;
+      const bool have = j < Ms;
+      const float4 mine4 = have ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bool dead = false;
+      for (int k = wave; k < nkept; k += NMS_NW) {
+        float4 kb;
+        if (k < NMS_KEPT_LDS) {
+          kb = kept_lds[k];
+        } else {   // beyond the LDS cache: written by wave 0 in an earlier step -- read past this CU's L1 (device-scope loads)
+          const float* g = out_boxes + ((long)n * top_k + k) * 4;
+          kb.x = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          kb.y = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          kb.z = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          kb.w = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (iou_gt(kb, mine4, iou_th)) dead = true;
       }
-      unsigned long long supp_by = 0ull;  // bit i set: earlier chunk member i would suppress me
-      for (int i = 0; i < 64; ++i) {
+      unsigned long long supp_by = 0ull;         // bit i set: earlier chunk member i would suppress me
+#pragma unroll
+      for (int t = 0; t < 64 / NMS_NW; ++t) {
+        const int i = wave * (64 / NMS_NW) + t;
         float4 o;
-        o.x = __shfl(mine.x, i, 64); o.y = __shfl(mine.y, i, 64); o.z = __shfl(mine.z, i, 64); o.w = __shfl(mine.w, i, 64);
-        if (i < lane && iou_gt(o, mine, iou_th)) supp_by |= 1ull << i;
+        o.x = __shfl(mine4.x, i, 64); o.y = __shfl(mine4.y, i, 64); o.z = __shfl(mine4.z, i, 64); o.w = __shfl(mine4.w, i, 64);
+        if (i < lane && iou_gt(o, mine4, iou_th)) supp_by |= 1ull << i;
       }
-      const unsigned long long alive_mask = __ballot(alive);
-      const unsigned lo32 = (unsigned)supp_by, hi32 = (unsigned)(supp_by >> 32);
-      unsigned long long keepmask = 0ull;
-      for (int L = 0; L < 64; ++L) {
-        const unsigned long long sb = ((unsigned long long)__shfl(hi32, L, 64) << 32) | __shfl(lo32, L, 64);
-        if (((alive_mask >> L) & 1ull) && (sb & keepmask) == 0ull) keepmask |= 1ull << L;
-      }
-      const bool kept = (keepmask >> lane) & 1ull;
-      const int pos = nkept + __popcll(keepmask & ((1ull << lane) - 1ull));
-      if (kept && pos < top_k) {
-        const unsigned long long key = keys[j];
-        const int ci = (int)(key & 0xffffffffu);
-        const int a = cand_anchor[ci];
-        ki[pos] = ci;
-        ka[pos] = a;
-        ob[pos] = mine;
-        os[pos] = sc[a];
-        ol[pos] = label ? (long long)label[(long)n * A + a] : 0ll;
-        if (pos < NMS_KEPT_LDS) kept_lds[pos] = mine;
+      part_supp[wave * 64 + lane] = supp_by;
+      const unsigned long long dead_mask = __ballot(dead);
+      if (lane == 0) part_dead[wave] = dead_mask;
+      __syncthreads();
+      if (wave == 0) {
+        unsigned long long dm = 0ull;
+#pragma unroll
+        for (int w = 0; w < NMS_NW; ++w) { supp_by |= part_supp[w * 64 + lane]; dm |= part_dead[w]; }   // (own part: OR-ed twice, harmless)
+        const unsigned long long alive_mask = __ballot(have) & ~dm;
+        const unsigned lo32 = (unsigned)supp_by, hi32 = (unsigned)(supp_by >> 32);
+        unsigned long long keepmask = 0ull;
+#pragma unroll
+        for (int L = 0; L < 64; ++L) {
+          const unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi32, L) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)lo32, L);
+          if (((alive_mask >> L) & 1ull) && (sb & keepmask) == 0ull) keepmask |= 1ull << L;
+        }
+        const bool kept = (keepmask >> lane) & 1ull;
+        const int pos = nkept + __popcll(keepmask & below);
+        if (kept && pos < top_k) {
+          const unsigned long long key = keys[j];
+          const int ci = (int)(key & 0xffffffffu);
+          const int a = cand_anchor[ci];
+          ki[pos] = ci;
+          ka[pos] = a;
+          ob[pos] = mine4;
+          os[pos] = sc[a];
+          ol[pos] = label ? (long long)label[(long)n * A + a] : 0ll;
+          if (pos < NMS_KEPT_LDS) kept_lds[pos] = mine4;
+        }
+        if (lane == 0) s_nkept = min(top_k, nkept + (int)__popcll(keepmask));
       }
       __threadfence_block();
-      nkept += __popcll(keepmask);
-      if (nkept > top_k) nkept = top_k;
+      __syncthreads();
     }
-    for (int k = nkept + lane; k < top_k; k += 64) {
-      ki[k] = -1; ka[k] = -1; ob[k] = make_float4(0.f, 0.f, 0.f, 0.f); os[k] = 0.f; ol[k] = -1;
+    if (wave == 0) {
+      const int nkept = s_nkept;
+      if (attempt == 0 && nkept < top_k) {       // the selection ran out: sort everything and start over
+        if (lane == 0) s_redo = 1;
+      } else {
+        for (int k = nkept + lane; k < top_k; k += 64) {
+          ki[k] = -1; ka[k] = -1; ob[k] = make_float4(0.f, 0.f, 0.f, 0.f); os[k] = 0.f; ol[k] = -1;
+        }
+        if (lane == 0) { counts[n] = nkept; if (n_cand) n_cand[n] = M; }
+      }
     }
-    if (lane == 0) { counts[n] = nkept; if (n_cand) n_cand[n] = M; }
+    __syncthreads();
+    if (attempt == 0 && !s_redo) break;     // (uniform)
+    __syncthreads();
   }
 }
 
@@ -453,7 +551,7 @@ extern "C" int mtbt_nms_batched(const float* boxes, const float* best_score, con
   const size_t lds = (size_t)NMS_KEPT_LDS * 16 + (keys_in_lds ? (size_t)P2 * 8 : 0);
   // one-time (per device) opt-in to the LARGEST dynamic LDS this kernel ever asks for: an idempotent driver attribute, not state
   if (int rc = mtbt_allow_lds(nms_kernel, NMS_KEPT_LDS * 16 + 128 * 1024)) return rc;
-  hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), boxes, best_score, best_label, A,
+  hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(NMS_NT), lds, reinterpret_cast<hipStream_t>(stream), boxes, best_score, best_label, A,
                      conf_th, iou_th, clamp_max, top_k, reinterpret_cast<long long*>(keep_idx), keep_anchor, out_boxes, out_scores,
                      reinterpret_cast<long long*>(out_labels), counts, n_cand, reinterpret_cast<char*>(workspace), per, P2, keys_in_lds);
   MTBT_LAUNCH_CHECK();

@@ -105,6 +105,32 @@ def test_nms_edge_cases():
     assert int(out["counts"][0]) == 0 and int(out["n_cand"][0]) == 0
 
 
+@pytest.mark.parametrize("kind", ["scattered", "narrow", "ties", "few_values"])
+def test_nms_preselection_bit_exact(kind):
+    """The kernel sorts only the candidates of the top score-histogram bins first and falls back to the full sort when
+    they run out: scattered boxes end inside the preselection, tied / quantised scores straddle and overflow its bins."""
+    A, top_k = 8400, 100
+    g = torch.Generator().manual_seed(11)
+    xy = torch.rand(A, 2, generator=g) * 600
+    wh = torch.rand(A, 2, generator=g) * 30 + 4
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(A, generator=g)
+    if kind == "narrow":
+        scores = 0.5 + (scores - 0.5) * 0.02                 # random-init logits: everything near 0.5
+    elif kind == "ties":
+        scores = torch.round(scores * 2000) / 2000          # many exact ties (stable order by candidate index)
+    elif kind == "few_values":
+        scores = torch.round(scores * 3) / 4 + 0.1          # four distinct values: the top bin alone overflows the selection
+    labels = torch.zeros(A, dtype=torch.int32)
+    out = pp.nms_batched(boxes[None].to(DEV), scores[None].to(DEV), labels[None].to(DEV), 640.0, 0.05, 0.6, top_k)
+    torch.cuda.synchronize()
+    k, anchors, kb, ks, _ = oracle_nms_image(boxes, scores, labels, 640.0, 0.05, 0.6, top_k)
+    n = int(out["counts"][0])
+    assert n == len(k) and torch.equal(out["keep_idx"][0, :n].cpu(), k)
+    assert torch.equal(out["keep_anchor"][0, :n].cpu().long(), anchors)
+    assert torch.equal(out["boxes"][0, :n].cpu(), kb) and torch.equal(out["scores"][0, :n].cpu(), ks)
+
+
 def test_nms_large_anchor_count_global_sort_path():
     """A = 33600 (1280x1280): the key array no longer fits LDS and is sorted in the workspace."""
     A = 33600

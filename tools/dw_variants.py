@@ -7,6 +7,7 @@ if "--build" in sys.argv:
                            "-I" + os.path.join(ROOT, "multitask_bonetumor_yolo_amd", "csrc"), "-Wno-unused-value", os.path.join(ROOT, "tools", "probes", "dw_variants.hip"), "-o", SO])
     sys.exit(0)
 import torch
+VARIANTS = [int(a) for a in sys.argv[1:] if a.isdigit()]
 lib = C.CDLL(SO)
 lib.dw_variant.restype = C.c_int
 lib.dw_variant.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
@@ -17,7 +18,7 @@ for (N, H, Cc) in [(16, 160, 96), (16, 80, 192)]:
     ref = None
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for rep in range(2):
-        for v in range(10):
+        for v in (VARIANTS or range(13)):
             y = torch.empty_like(x)
             rc = lib.dw_variant(v, x.data_ptr(), w.data_ptr(), b.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, y.data_ptr(), N, H, H, Cc, s)
             if rc == -100:
