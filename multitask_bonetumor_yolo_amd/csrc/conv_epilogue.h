@@ -31,9 +31,15 @@ __device__ __forceinline__ void stage_affine(const ConvP& p, float* aff, int cba
 // slab pixel (without the channel), false if the pixel is outside the output.
 // TRAIN = false compiles the training epilogues (y2, MTBT_ACT_D*) out: the direct 3x3 kernels never need them (they are used by the 1x1
 // GEMMs fc1 / fc2-dgrad only) and lost 13 % with the extra code present (tools/conv_ab.py, same box, same run).
-template <typename T, int TC, int FC, int FP, bool TRAIN = true, typename AddrFn>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
-                                              int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr) {
+//
+// ACT / VEC: the activation code and "every 8-channel piece is one aligned 16-byte access" as COMPILE-TIME constants of the body; the
+// dispatcher below switches on them ONCE per call.  With the activation switch inside the fully unrolled per-element loops (and the
+// ragged-tail code next to every vector store) the epilogue of the 128x64 tile was ~12 000 instructions with 1 160 scalar branches for a
+// main loop of 16 MFMAs: tens of KiB of code streamed through the instruction cache per tile and a taken branch every few instructions.
+// ACT = -1 is the run-time form (ragged outputs: the nc-channel class conv, the 66-wide detect map).
+template <typename T, int TC, int FC, int FP, bool TRAIN, int ACT, bool VEC, typename AddrFn>
+__device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
+                                                   int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr) {
   constexpr int WCH = FC * 16;
   constexpr int PITCH = WCH * 4 + 16;
   constexpr int C8 = WCH / 8;
@@ -41,8 +47,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
   typedef typename half_of<T>::type HT;   // 16-bit output element (bf16 / fp16) when the output is not fp32
   const int lr = lane & 15, lq = lane >> 4;
   const bool has_scale = p.scale != nullptr;
+  const int act = ACT >= 0 ? ACT : p.act;
   // training epilogues keep the PRE-activation in the slab and finish in the row pass: y2 (second output) / MTBT_ACT_D* (multiply by act'(res))
-  const bool deriv = TRAIN && p.act >= MTBT_ACT_DSILU;
+  const bool deriv = TRAIN && act >= MTBT_ACT_DSILU;
   const bool late_act = TRAIN && (p.y2 != nullptr || deriv);
 #pragma clang loop unroll(full)  // must unroll: a runtime j would put the whole accumulator array in scratch
   for (int j = 0; j < FP; ++j) {
@@ -57,7 +64,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       }
       v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
       if (!late_act) {   // the usual case: activation here, on the accumulators (wave-uniform branch)
-        v.x = act_apply(v.x, p.act); v.y = act_apply(v.y, p.act); v.z = act_apply(v.z, p.act); v.w = act_apply(v.w, p.act);
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
       }
       *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
     }
@@ -75,22 +82,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       const float4 lo = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32);
       const float4 hi = *reinterpret_cast<const float4*>(slab + row * PITCH + c8 * 32 + 16);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      if (p.vec_ok && ch + 8 <= p.K) {
+      if (VEC || (p.vec_ok && ch + 8 <= p.K)) {
         if (TRAIN && p.y2) {   // training forward: keep the pre-activation next to the activated output
           if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y2) + yoff, v);
           else st8<HT>(reinterpret_cast<HT*>(p.y2) + yoff, v);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], p.act);
+          for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], act);
         }
         if (p.res) {
           float r[8];
           ld8<T>(reinterpret_cast<const T*>(p.res) + roff, r);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = deriv ? v[e] * act_grad(r[e], p.act) : v[e] + r[e];
+          for (int e = 0; e < 8; ++e) v[e] = deriv ? v[e] * act_grad(r[e], act) : v[e] + r[e];
         }
         if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y) + yoff, v);
         else st8<HT>(reinterpret_cast<HT*>(p.y) + yoff, v);
-      } else {
+      } else if (!VEC) {
         // unaligned / ragged channel tail (e.g. the nc-channel class conv, the 66-wide detect map)
         const int lim = (p.out_mode == MTBT_OUT_CONVT2X2) ? (ch / (p.K >> 2) + 1) * (p.K >> 2) : p.K;
         for (int e = 0; e < 8 && ch + e < lim; ++e) {
@@ -99,10 +106,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
             if (p.out_f32) reinterpret_cast<float*>(p.y2)[yoff + e] = u;
             else st_elem<HT>(reinterpret_cast<HT*>(p.y2) + yoff + e, u);
           }
-          if (TRAIN && p.y2) u = act_apply(u, p.act);
+          if (TRAIN && p.y2) u = act_apply(u, act);
           if (p.res) {
             const float r = ld_elem<T>(reinterpret_cast<const T*>(p.res) + roff + e);
-            u = deriv ? u * act_grad(r, p.act) : u + r;
+            u = deriv ? u * act_grad(r, act) : u + r;
           }
           if (p.out_f32) reinterpret_cast<float*>(p.y)[yoff + e] = u;
           else st_elem<HT>(reinterpret_cast<HT*>(p.y) + yoff + e, u);
@@ -111,6 +118,131 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
   }
+}
+
+// The FAST body: 16-bit NHWC output whose pixels are an arithmetic sequence per slab (pixel(j, row) = pix0 + j * jstep + row, element offset
+// bias + pixel * pitch + channel), every piece one aligned 16-byte access, activation a compile-time constant.  Everything that does not
+// depend on the slab j -- the lane's rows / channel pieces of the row pass, their offsets and channel bound, the scale / shift vectors -- is
+// computed once; per slab what is left is FC x (4 FMA + activation + one b128 LDS write) and ITER x (two b128 LDS reads, the pack, one
+// 16-byte store).  For the short-K 1x1 GEMMs (K = 96 .. 384: 3 .. 12 K-steps of 16 MFMAs) the general body above executed more
+// instructions than the main loop.
+// MODE 0: y = act(affine) (+ res);  1: y2 = affine (pre-activation), y = act(affine) (+ res);  2: y = affine * act'(res)  (ACT = MTBT_ACT_D*)
+struct EpiSeq { long pix0; int jstep; long npix; long ybias, rbias; };
+
+template <typename T, int TC, int FC, int FP, int ACT, int MODE>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase, int chl0, int lane,
+                                                   const EpiSeq q) {
+  constexpr int WCH = FC * 16;
+  constexpr int PITCH = WCH * 4 + 16;
+  constexpr int C8 = WCH / 8;
+  constexpr int ITER = (16 * C8 + 63) / 64;
+  constexpr bool HOIST = FC <= 4;          // scale / shift of the lane's channels in registers across the slabs
+  typedef typename half_of<T>::type HT;
+  const int lr = lane & 15, lq = lane >> 4;
+  float4 sc[HOIST ? FC : 1], sh[HOIST ? FC : 1];
+  if (HOIST) {
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+      const int cl = chl0 + i * 16 + lq * 4;
+      sc[HOIST ? i : 0] = *reinterpret_cast<const float4*>(aff + cl);
+      sh[HOIST ? i : 0] = *reinterpret_cast<const float4*>(aff + TC + cl);
+    }
+  }
+  long yo[ITER], ro[ITER], px[ITER];
+  int so[ITER];
+  bool ok[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / C8, c8 = idx - row * C8;
+    const int ch = cbase + chl0 + c8 * 8;
+    ok[it] = ((16 * C8) % 64 == 0 || idx < 16 * C8) && ch < p.K;
+    px[it] = q.pix0 + row;
+    yo[it] = q.ybias + px[it] * p.ldy + ch;
+    ro[it] = q.rbias + px[it] * p.ldr + ch;
+    so[it] = row * PITCH + c8 * 32;
+  }
+  const long ystep = (long)q.jstep * p.ldy, rstep = (long)q.jstep * p.ldr;
+  const bool has_res = p.res != nullptr;
+  HT* const yp = reinterpret_cast<HT*>(p.y);
+  HT* const y2p = reinterpret_cast<HT*>(p.y2);
+  const T* const rp = reinterpret_cast<const T*>(p.res);
+#pragma clang loop unroll(full)
+  for (int j = 0; j < FP; ++j) {
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+      float4 s4, h4;
+      if (HOIST) { s4 = sc[HOIST ? i : 0]; h4 = sh[HOIST ? i : 0]; }
+      else {
+        const int cl = chl0 + i * 16 + lq * 4;
+        s4 = *reinterpret_cast<const float4*>(aff + cl);
+        h4 = *reinterpret_cast<const float4*>(aff + TC + cl);
+      }
+      float4 v;
+      v.x = fmaf(acc[i][j][0], s4.x, h4.x); v.y = fmaf(acc[i][j][1], s4.y, h4.y);
+      v.z = fmaf(acc[i][j][2], s4.z, h4.z); v.w = fmaf(acc[i][j][3], s4.w, h4.w);
+      if (MODE == 0) { v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT); }
+      *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local hand-off through LDS (see the general body)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (!ok[it] || px[it] + (long)j * q.jstep >= q.npix) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(slab + so[it]);
+      const float4 hi = *reinterpret_cast<const float4*>(slab + so[it] + 16);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const long yoff = yo[it] + j * ystep, roff = ro[it] + j * rstep;
+      if (MODE == 1) {
+        st8<HT>(y2p + yoff, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], ACT);
+      }
+      if (MODE == 2) {
+        float r[8];
+        ld8<T>(rp + roff, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= act_grad(r[e], ACT);
+      } else if (has_res) {
+        float r[8];
+        ld8<T>(rp + roff, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      st8<HT>(yp + yoff, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
+  }
+}
+
+// Dispatcher: ONE switch per call.  `seq` non-null = the caller's output pixels form the arithmetic sequence the fast body wants.
+template <typename T, int TC, int FC, int FP, bool TRAIN = true, typename AddrFn>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
+                                              int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq* seq = nullptr) {
+#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV>(p, acc, slab, aff, cbase, chl0, lane, *seq)
+  const bool fast = seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
+  if (fast && !(TRAIN && p.y2)) {
+    switch (p.act) {
+      case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;
+      case MTBT_ACT_SILU: MTBT_FAST(MTBT_ACT_SILU, 0); return;
+      case MTBT_ACT_ELU: MTBT_FAST(MTBT_ACT_ELU, 0); return;
+      case MTBT_ACT_GELU: MTBT_FAST(MTBT_ACT_GELU, 0); return;
+      case MTBT_ACT_GELU_POLY: MTBT_FAST(MTBT_ACT_GELU_POLY, 0); return;
+      case MTBT_ACT_DSILU: if (TRAIN) { MTBT_FAST(MTBT_ACT_DSILU, 2); return; } break;
+      case MTBT_ACT_DELU: if (TRAIN) { MTBT_FAST(MTBT_ACT_DELU, 2); return; } break;
+      case MTBT_ACT_DGELU: if (TRAIN) { MTBT_FAST(MTBT_ACT_DGELU, 2); return; } break;
+      default: break;
+    }
+  } else if (TRAIN && fast) {   // second output = the pre-activation (training forward of fc1)
+    switch (p.act) {
+      case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 1); return;
+      case MTBT_ACT_GELU: MTBT_FAST(MTBT_ACT_GELU, 1); return;
+      case MTBT_ACT_GELU_POLY: MTBT_FAST(MTBT_ACT_GELU_POLY, 1); return;
+      default: break;
+    }
+  }
+#undef MTBT_FAST
+  // everything else (fp32 / ragged / transposed-conv outputs, rare activation + mode pairs): the general body, run-time activation
+  conv_epilogue_body<T, TC, FC, FP, TRAIN, -1, false>(p, acc, slab, aff, cbase, chl0, lane, addr);
 }
 
 }  // namespace

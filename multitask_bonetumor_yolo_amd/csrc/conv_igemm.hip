@@ -28,9 +28,11 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
   else tc = 32;
   const long ct = (K + tc - 1) / tc;
   if (taps == 1 && (pol & 1)) {
+    // round-2 sweep (profiles/r02_f_conv_tune_1x1.txt, after the epilogue was split by activation): 128x128 tiles once the grid holds >= 4 of
+    // them per CU (fc1 of every stage, the C2f 1x1s at P3: 6-18 % faster than 128x64), 128x64 below that; 64-byte K-steps for short rows
     *TC = tc;
-    *TP = (tc == 128) ? 64 : 128;
-    *narrow = (C * es <= 1536) ? 1 : 0;
+    *TP = (tc != 128 || ((M + 127) / 128) * ct >= 1024) ? 128 : 64;
+    *narrow = (C * es <= (tc != 128 ? 1536 : (*TP == 128 ? 1024 : 512))) ? 1 : 0;
     return;
   }
   *narrow = 0;
@@ -40,7 +42,9 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
     return;
   }
   if (K <= 64) { *TC = K > 32 ? 64 : 32; *TP = 64; return; }
-  if (((M + 127) / 128) * ct >= 512) { *TC = tc; *TP = 128; return; }
+  // (round-2 sweep, profiles/r02_f_conv_tune_3x3.txt: one 128-pixel tile per CU is already enough -- c2f_p4.m 3x3 192->192 @40: 40.3 -> 31.6 us)
+  if (((M + 127) / 128) * ct >= 256) { *TC = tc; *TP = 128; return; }
+  if (((M + 63) / 64) * ct >= 256) { *TC = tc; *TP = 64; return; }
   *TC = (tc == 96) ? 96 : 64;
   *TP = 64;
 }

@@ -3,8 +3,8 @@
 #include "conv3x3_direct.inc"
 
 int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s) {
-  if (wide) return nbuf >= 3 ? dispatch_tile<float, 128, 3>(p, TC, TP, s) : dispatch_tile<float, 128, 2>(p, TC, TP, s);
-  return nbuf >= 3 ? dispatch_tile<float, 64, 3>(p, TC, TP, s) : dispatch_tile<float, 64, 2>(p, TC, TP, s);
+  (void)nbuf;
+  return wide ? dispatch_tile<float, 128, 2>(p, TC, TP, s) : dispatch_tile<float, 64, 2>(p, TC, TP, s);
 }
 
 int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s) {

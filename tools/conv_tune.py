@@ -64,8 +64,8 @@ def bench(shape, hint, dtype=torch.bfloat16, iters=20):
 
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
-    hints = [(0, 0, 0, 0)] + [(nb, tc, tp, nar) for tc, tp in [(128, 256), (64, 256), (128, 128), (128, 64), (64, 128), (96, 128), (64, 64)]
-                              for nar in (0, 1) for nb in (2, 3, 4) if not (nar == 0 and nb == 4)]
+    hints = [(0, 0, 0, 0)] + [(2, tc, tp, nar) for tc, tp in [(128, 128), (128, 64), (64, 128), (96, 128), (96, 64), (64, 64), (32, 128)]
+                              for nar in (0, 1)]   # (two LDS stages: the deeper pipelines and the 256-pixel tiles are no longer built)
     for name, shape in SHAPES.items():
         if flt and flt not in name:
             continue
