@@ -5,7 +5,7 @@ from multitask_bonetumor_yolo_amd import _lib as L
 from multitask_bonetumor_yolo_amd.engine import Act, Plan
 from multitask_bonetumor_yolo_amd.model import _permute_hidden
 dev = torch.device("cuda:0")
-for (M, D, H) in [(25600, 384, 40), (102400, 384, 80), (25600, 192, 160 // 2)]:
+for (M, D, H) in [(25600, 384, 40), (102400, 192, 80), (409600, 96, 160)]:
     N = M // (H * H)
     t = torch.randn(N, H, H, D, device=dev).bfloat16()
     res = torch.randn(N, H, H, D, device=dev).bfloat16()

@@ -1,0 +1,34 @@
+"""Ablation timing of the fused ConvNeXt MLP (tools/probes/mlp_variants.hip; `--build` compiles it with hipcc).  One box, one process."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tools", "probes", "libmlpv.so")
+if "--build" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "multitask_bonetumor_yolo_amd", "csrc"), "-Wno-unused-value", os.path.join(ROOT, "tools", "probes", "mlp_variants.hip"), "-o", SO])
+    sys.exit(0)
+import torch
+sys.path.insert(0, ROOT)
+from multitask_bonetumor_yolo_amd.model import _permute_hidden
+lib = C.CDLL(SO)
+lib.mlp_variant.restype = C.c_int
+lib.mlp_variant.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_long, C.c_int, C.c_void_p]
+dev = torch.device("cuda:0")
+NAMES = {0: "full", 1: "no GELU", 2: "no GEMM2", 4: "no GEMM1", 8: "no weight DMA", 6: "no MFMA", 7: "no MFMA, no GELU", 15: "skeleton (no DMA / MFMA / GELU)", 32: "no stores"}
+for (M, D) in [(25600, 384), (102400, 192), (409600, 96)]:
+    t = torch.randn(M, D, device=dev).bfloat16(); res = torch.randn(M, D, device=dev).bfloat16()
+    w1 = (torch.randn(4 * D, D, device=dev) / D ** 0.5).bfloat16()
+    w2 = _permute_hidden((torch.randn(D, 4 * D, device=dev) / (4 * D) ** 0.5 * 0.1).bfloat16()).contiguous()
+    b1, b2 = torch.randn(4 * D, device=dev) * 0.1, torch.randn(D, device=dev) * 0.1
+    y = torch.empty_like(t)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rep in range(2):
+        for dbg, name in NAMES.items():
+            args = (dbg, t.data_ptr(), res.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), M, D, s)
+            for _ in range(3):
+                assert lib.mlp_variant(*args) == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                lib.mlp_variant(*args)
+            e1.record(); torch.cuda.synchronize()
+            print(f"D={D} M={M} {name:34s} {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us", flush=True)
