@@ -5,8 +5,8 @@
 //
 // The general kernel (postprocess.hip) re-reads the 18x18x32 prototype halo patch for every box: at 100
 // boxes x 100 tiles x 16 images that is ~6.5 GB of L2 traffic, and its per-pixel index arithmetic + exp
-// made it VALU-bound at 0.6 TB/s of output.  Here a workgroup owns one 64x64 output tile of one image:
-//   1. the prototype halo patch (18x18 low-res pixels x 32 channels, coordinates CLAMPED to the image so the
+// made it VALU-bound at 0.6 TB/s of output.  Here a workgroup owns one output tile of one image (128 x 32, or 64 x 64 for odd widths):
+//   1. the prototype halo patch (tile / 4 + halo low-res pixels x 32 channels, coordinates CLAMPED to the image so the
 //      edge rule of torch's bilinear falls out of the uniform interior formula) is staged in LDS once;
 //   2. boxes are processed 16 at a time: coefficients [16 x 32] x patch [32 x 324] on the fp32 MFMA
 //      (rows = boxes, columns = low-res pixels, 8 K-steps of 4 channels) -> low-res masks in LDS;
@@ -32,13 +32,18 @@ struct MaskX4P {
 };
 
 constexpr int NM = 32;          // prototype channels
-constexpr int PW = 18;          // patch edge (16 + halo)
-constexpr int NPX = PW * PW;    // 324 low-res pixels
-constexpr int NPXP = 336;       // padded to 21 MFMA column groups
 constexpr int PPITCH = NM + 1;  // patch row pitch (floats): conflict-free column reads
-constexpr int LPITCH = NPXP + 4;
 
+// LW x LH low-res pixels per tile = a 4 LW x 4 LH output tile.  16 x 16 (64 x 64 outputs) is the general shape; 32 x 8 (128 x 32 outputs)
+// when the width allows: a mask row of the tile is then a whole 128-byte line -- with 64-byte rows two workgroups each wrote HALF of every
+// line of the uint8 masks (2.2 TB/s of output at 640x640; the kernel is nothing but that write).
+template <int LW, int LH>
 __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
+  constexpr int PW = LW + 2, PH = LH + 2;          // patch = tile + halo
+  constexpr int NPX = PW * PH;
+  constexpr int NPXP = (NPX + 15) / 16 * 16;       // padded to whole MFMA column groups
+  constexpr int LPITCH = NPXP + 4;
+  constexpr int SEGS = LW / 4;                     // 16-pixel output segments per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* patch = reinterpret_cast<float*>(smem);       // [NPXP][PPITCH]
   float* coef = patch + NPXP * PPITCH;                 // [16][PPITCH]
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y;
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-  const int lx_base = tx * 16 - 1, ly_base = ty * 16 - 1;
+  const int lx_base = tx * LW - 1, ly_base = ty * LH - 1;
   const int cnt = p.counts ? min(p.counts[n], p.K) : p.K;
 
   // 1. stage the clamped halo patch
@@ -63,8 +68,8 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
 
-  const int row = tid >> 2, seg = tid & 3;  // upsample role: output row of the tile, 16-pixel segment
-  const int oy = ty * 64 + row, ox0 = tx * 64 + seg * 16;
+  const int row = tid / SEGS, seg = tid % SEGS;  // upsample role: output row of the tile (4 LH rows x SEGS segments = 256 threads), 16-pixel segment
+  const int oy = ty * (4 * LH) + row, ox0 = tx * (4 * LW) + seg * 16;
   // vertical taps of this thread's row (x4): low row index inside the patch and weight
   const int iy = (row + 2) >> 2;
   const float wy1 = ((row + 2) & 3) * 0.25f + 0.125f, wy0 = 1.0f - wy1;
@@ -143,6 +148,19 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
 }  // namespace
 
 // Returns MTBT_OK if the fast path applied, 1 if the shape is not the x4 case (caller falls back).
+template <int LW, int LH>
+static int launch_mask_x4(MaskX4P& p, const mtbt_mask_args* a, hipStream_t stream) {
+  static_assert(LW * LH == 256 && (LW / 4) * (4 * LH) == 256, "256 threads: one per (output row, 16-pixel segment)");
+  constexpr int NPXP = ((LW + 2) * (LH + 2) + 15) / 16 * 16;
+  p.tiles_x = a->Wout / (4 * LW);
+  p.tiles_y = (a->Hout + 4 * LH - 1) / (4 * LH);
+  const size_t lds = (size_t)(NPXP * PPITCH + 16 * PPITCH + 16 * (NPXP + 4)) * sizeof(float);
+  if (int rc = mtbt_allow_lds(mask_x4_kernel<LW, LH>, (int)lds)) return rc;
+  hipLaunchKernelGGL((mask_x4_kernel<LW, LH>), dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
 int mtbt_mask_x4_try(const mtbt_mask_args* a, hipStream_t stream) {
   if (a->nm != NM || a->Hout != 4 * a->hp || a->Wout != 4 * a->wp || a->Wout % 64 || a->Hout % 4) return 1;
   MaskX4P p;
@@ -150,11 +168,5 @@ int mtbt_mask_x4_try(const mtbt_mask_args* a, hipStream_t stream) {
   p.gather = a->gather_idx; p.counts = a->counts; p.bias = a->bias;
   p.N = a->N; p.K = a->K; p.hp = a->hp; p.wp = a->wp; p.Hout = a->Hout; p.Wout = a->Wout;
   p.logits = a->logits; p.masks = a->masks;
-  p.tiles_x = a->Wout / 64;
-  p.tiles_y = (a->Hout + 63) / 64;
-  const size_t lds = (size_t)(NPXP * PPITCH + 16 * PPITCH + 16 * LPITCH) * sizeof(float);
-  if (int rc = mtbt_allow_lds(mask_x4_kernel, (int)lds)) return rc;
-  hipLaunchKernelGGL(mask_x4_kernel, dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
-  MTBT_LAUNCH_CHECK();
-  return MTBT_OK;
+  return a->Wout % 128 == 0 ? launch_mask_x4<32, 8>(p, a, stream) : launch_mask_x4<16, 16>(p, a, stream);
 }
