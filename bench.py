@@ -317,7 +317,7 @@ def main():
                             "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / peak_hbm, 4), "ms_per_step": round(v[1], 3),
                             "algorithmic_bytes_per_launch": round(v[0] / v[2]), "traffic": (traffic_all or {}).get(k)} for k, v in hbm.items()}
         line = {
-            "metric": "images/sec at 640x640 multitask fwd (det+seg+cls) + decode/NMS/masks",
+            "metric": f"images/sec at {IMG}x{IMG} multitask fwd (det+seg+cls) + decode/NMS/masks",
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -93,9 +93,26 @@ typedef struct mtbt_conv_args {
                           bit2 direct 3x3 kernel, bit3 row-reuse 3x3 everywhere, bit4 never, bit5 64-channel direct tiles): the host's
                           A/B knob, passed per call -- the library reads no environment variables and keeps no mutable global state */
   int32_t debug;       /* ablation bits, honoured by -DMTBT_CONV_ABLATION builds only */
+  /* Optional per-channel COLUMN SUMS of the output the call stores (values as rounded to out_dtype), from the conv epilogue itself:
+   *   colsum[k] (+)= sum_p (y[p][k] - colsum_shift[k]);   colsum_sq: colsum[K + k] (+)= sum_p (y[p][k] - colsum_shift[k])^2
+   * Replaces a separate pass over y for nn.BatchNorm2d's batch statistics (main_model.py:95,126-136: the conv in front of the BatchNorm;
+   * shift = the running mean keeps sum / sum of squares well conditioned) and for bias gradients (d fc1.bias = sum_p of the
+   * fc2-dgrad * GELU' output, main_model.py:21-26 [timm Mlp]).  MTBT_OUT_NHWC only; colsum NULL = off.  Deterministic (fixed-order
+   * partial rows in colsum_ws -- rows x pitch floats as reported by mtbt_conv_colsum_layout, never more than
+   * mtbt_conv_colsum_workspace_bytes -- then one wave per channel). */
+  float* colsum;             /* [K] or [2K] f32 */
+  const float* colsum_shift; /* [K] f32 or NULL (= 0) */
+  int32_t colsum_sq;         /* != 0: also the sum of squares */
+  int32_t colsum_accumulate; /* != 0: add to colsum instead of overwriting */
+  void* colsum_ws;
+  int64_t colsum_ws_bytes;
 } mtbt_conv_args;
 
 int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream);
+int64_t mtbt_conv_colsum_workspace_bytes(int64_t pixels /* N*Ho*Wo */, int K, int with_squares);
+/* colsum may be NULL with colsum_ws set: only the partial rows are written (rows x pitch floats, a row = [sums (K) | sums of squares (K)]
+ * of one pixel tile's wave row) for a consumer that reduces them itself; this reports the layout a call with the same arguments produces. */
+int mtbt_conv_colsum_layout(const mtbt_conv_args* a, int64_t* rows, int32_t* pitch);
 
 /* ---------------------------------------------------------------------------------------------
  * ConvNeXt stem: Conv2d(3,Cout,4,stride 4,bias) on the caller's NCHW fp32 image + LayerNorm2d.
@@ -422,6 +439,18 @@ int mtbt_dwconv_nhwc_train(const void* x, const void* w, const float* bias, cons
 int mtbt_bn_forward_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, int use_running,
                          float* stats, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The same with the batch statistics taken from the column sums the producing conv accumulated in its epilogue (mtbt_conv_args.colsum
+ * with colsum_sq): sums [2C] = sum (x - shift), sum (x - shift)^2.  shift [C] or NULL; it may alias running_mean.  One pass over x
+ * instead of two. */
+int mtbt_bn_forward_sums_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, const float* sums,
+                              const float* shift, float* stats, void* stream);
+
+/* ... and straight from the conv's partial rows (second level and statistics in one launch). */
+int mtbt_bn_forward_partials_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, const float* partial,
+                                  int64_t rows, int32_t pitch, const float* shift, float* stats, void* stream);
 
 /* Backward of activation + BatchNorm2d in one operator: dy = gradient of the ACTIVATED output (rows of dy_pixel_stride elements),
  * x = the conv output the forward normalised (dense), stats as written by mtbt_bn_forward_nhwc.

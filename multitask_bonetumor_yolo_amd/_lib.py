@@ -25,6 +25,8 @@ class ConvArgs(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("act", C.c_int32), ("out_mode", C.c_int32), ("tile_hint", C.c_int32), ("y2", C.c_void_p),
         ("policy", C.c_int32), ("debug", C.c_int32),
+        ("colsum", C.c_void_p), ("colsum_shift", C.c_void_p), ("colsum_sq", C.c_int32), ("colsum_accumulate", C.c_int32),
+        ("colsum_ws", C.c_void_p), ("colsum_ws_bytes", C.c_int64),
     ]
 
 
@@ -135,6 +137,12 @@ SYMBOLS = {
                                + [C.c_int] * 6 + [C.c_void_p]),
     "mtbt_bn_forward_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mtbt_bn_forward_sums_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtbt_conv_colsum_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "mtbt_conv_colsum_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtbt_bn_forward_partials_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtbt_bn_backward_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "mtbt_bn_backward_nhwc": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 3
                               + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -91,6 +91,45 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, cons
   }
 }
 
+// batch statistics straight from the conv epilogue's PARTIAL rows ([rows][pitch]: sum (x - s) in [0, C), sum (x - s)^2 in [C, 2C)): one wave per
+// channel, lanes stride over the rows, butterfly (fixed order) -- the second level of the column sums and the statistics in one launch
+__global__ __launch_bounds__(256) void bn_stats_from_partials_kernel(const float* __restrict__ partial, int rows, int pitch, const float* __restrict__ shift,
+                                                                     long pixels, int C, float* __restrict__ mean, float* __restrict__ var,
+                                                                     float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;                                   // whole waves leave together
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = lane; r < rows; r += 64) { s1 += partial[(long)r * pitch + c]; s2 += partial[(long)r * pitch + C + c]; }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) {
+    const float n = (float)pixels;
+    const float sh = shift ? shift[c] : 0.f;            // (may BE running_mean[c]: read before it is updated below)
+    const float m1 = s1 / n;
+    const float mu = sh + m1;
+    const float m2 = fmaxf(s2 - n * m1 * m1, 0.f);
+    mean[c] = mu;
+    var[c] = m2 / n;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (pixels > 1 ? m2 / (float)(pixels - 1) : m2 / n);
+  }
+}
+
+// batch statistics from the column sums the producing conv's epilogue accumulated (mtbt_conv_args.colsum): sum (x - s), sum (x - s)^2
+__global__ void bn_stats_from_sums_kernel(const float* __restrict__ sums, const float* __restrict__ shift, long pixels, int C, float* __restrict__ mean,
+                                          float* __restrict__ var, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float n = (float)pixels;
+  const float sh = shift ? shift[c] : 0.f;          // (may BE running_mean[c]: read before it is updated below)
+  const float m1 = sums[c] / n;
+  const float mu = sh + m1;
+  const float m2 = fmaxf(sums[C + c] - n * m1 * m1, 0.f);   // sum (x - mu)^2
+  mean[c] = mu;
+  var[c] = m2 / n;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (pixels > 1 ? m2 / (float)(pixels - 1) : m2 / n);
+}
+
 __global__ void bn_copy_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mean, float* __restrict__ var, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) { mean[c] = rm[c]; var[c] = rv[c]; }
@@ -137,6 +176,61 @@ extern "C" int mtbt_bn_forward_nhwc(const void* x, void* y, int32_t y_pixel_stri
     hipLaunchKernelGGL(bn_combine_stats_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, (int)nb, C, (long)pixels, mean, var, running_mean,
                        running_var, momentum);
   }
+  if (dtype == MTBT_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+// The same with the statistics taken from column sums (mtbt_conv_args.colsum of the conv that produced x): sums [2C] = sum (x - shift),
+// sum (x - shift)^2 over the `pixels` rows; shift [C] or NULL, and it may alias running_mean (each channel is read before it is updated).
+extern "C" int mtbt_bn_forward_sums_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
+                                         float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype,
+                                         const float* sums, const float* shift, float* stats, void* stream) {
+  if (!x || !y || !gamma || !beta || !stats || !sums || pixels <= 0 || C <= 0 || C % 8 || C > 2048 || y_pixel_stride < C || y_pixel_stride % 8) return MTBT_EINVAL;
+  if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
+  if (act < MTBT_ACT_NONE || act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || !aligned16(stats)) return MTBT_EALIGN;
+  const int CH8 = C / 8;
+  if (CH8 > 256) return MTBT_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* mean = stats;
+  float* var = stats + C;
+  hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, sums, shift, (long)pixels, C, mean, var, running_mean,
+                     running_var, momentum);
+  const long total = pixels * CH8;
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (dtype == MTBT_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+// ... and from the conv's partial rows (mtbt_conv_colsum_layout gives rows / pitch): no separate second level.
+extern "C" int mtbt_bn_forward_partials_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype,
+                                             const float* partial, int64_t rows, int32_t pitch, const float* shift, float* stats, void* stream) {
+  if (!x || !y || !gamma || !beta || !stats || !partial || rows <= 0 || rows > 0x7fffffffL || pitch < 2 * C || pixels <= 0 || C <= 0 || C % 8 || C > 2048 ||
+      y_pixel_stride < C || y_pixel_stride % 8)
+    return MTBT_EINVAL;
+  if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
+  if (act < MTBT_ACT_NONE || act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || !aligned16(stats)) return MTBT_EALIGN;
+  const int CH8 = C / 8;
+  if (CH8 > 256) return MTBT_EINVAL;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* mean = stats;
+  float* var = stats + C;
+  hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, (int)rows, pitch, shift, (long)pixels, C, mean, var,
+                     running_mean, running_var, momentum);
+  const long total = pixels * CH8;
+  long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
   if (dtype == MTBT_F32)
     hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, (float*)y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride);
   else

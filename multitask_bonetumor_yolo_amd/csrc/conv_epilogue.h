@@ -27,6 +27,33 @@ __device__ __forceinline__ void stage_affine(const ConvP& p, float* aff, int cba
   }
 }
 
+// ---- per-channel column sums of the stored output, accumulated in the row pass ----
+// In the row pass a lane holds 8 consecutive channels (piece c8 = lane % C8, constant over the slabs when C8 divides 64) of one pixel per
+// (slab, iteration): the sums of ITS pixels stay in 8 (+ 8) registers; at the end the lanes that share c8 (lane bits log2(C8) .. 5) are added
+// by xor-shuffles and lanes 0 .. C8-1 write the wave's partial row.  The values summed are the ones STORED (rounded to the output type) minus
+// an optional per-channel shift (BatchNorm: the running mean, which keeps sum / sum-of-squares well conditioned).  Deterministic.
+template <typename OUT> __device__ __forceinline__ float stored_value(float v);
+template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return __uint_as_float((unsigned)f2bf(v) << 16); }
+template <> __device__ __forceinline__ float stored_value<f16_t>(float v) { return h2f(f2h(v)); }
+
+template <int C8>
+__device__ __forceinline__ void colsum_flush(const ConvP& p, float (&cs)[8], float (&cq)[8], long srow, int ch, bool ch_ok, int lane) {
+  static_assert((C8 & (C8 - 1)) == 0 && C8 <= 64, "lanes sharing a channel piece differ in whole lane bits");
+#pragma unroll
+  for (int o = C8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs[e] += __shfl_xor(cs[e], o, 64); cq[e] += __shfl_xor(cq[e], o, 64); }
+  }
+  if (lane < C8 && ch_ok) {
+    float* row = p.cs_part + srow * p.cs_pitch + ch;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (ch + e < p.K) { row[e] = cs[e]; if (p.cs_sq) row[p.K + e] = cq[e]; }
+    }
+  }
+}
+
 // AddrFn: bool operator()(int j, int row, long& pixel_offset_y, long& pixel_offset_res) -- offsets in elements of the
 // slab pixel (without the channel), false if the pixel is outside the output.
 // TRAIN = false compiles the training epilogues (y2, MTBT_ACT_D*) out: the direct 3x3 kernels never need them (they are used by the 1x1
@@ -39,7 +66,7 @@ __device__ __forceinline__ void stage_affine(const ConvP& p, float* aff, int cba
 // ACT = -1 is the run-time form (ragged outputs: the nc-channel class conv, the 66-wide detect map).
 template <typename T, int TC, int FC, int FP, bool TRAIN, int ACT, bool VEC, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
-                                                   int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr) {
+                                                   int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, long srow) {
   constexpr int WCH = FC * 16;
   constexpr int PITCH = WCH * 4 + 16;
   constexpr int C8 = WCH / 8;
@@ -51,6 +78,13 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
   // training epilogues keep the PRE-activation in the slab and finish in the row pass: y2 (second output) / MTBT_ACT_D* (multiply by act'(res))
   const bool deriv = TRAIN && act >= MTBT_ACT_DSILU;
   const bool late_act = TRAIN && (p.y2 != nullptr || deriv);
+  // column sums (see colsum_flush): this lane's channel piece is the same in every slab / iteration when C8 is a power of two
+  constexpr bool CS_OK = (C8 & (C8 - 1)) == 0;
+  const bool csum = CS_OK && p.cs_part != nullptr && srow >= 0;
+  const int cs_ch = cbase + chl0 + (lane % C8) * 8;
+  float cs[8], cq[8], csh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; csh[e] = (csum && p.cs_shift && cs_ch + e < p.K) ? p.cs_shift[cs_ch + e] : 0.f; }
 #pragma clang loop unroll(full)  // must unroll: a runtime j would put the whole accumulator array in scratch
   for (int j = 0; j < FP; ++j) {
 #pragma unroll
@@ -97,10 +131,16 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
         }
         if (p.out_f32) st8<float>(reinterpret_cast<float*>(p.y) + yoff, v);
         else st8<HT>(reinterpret_cast<HT*>(p.y) + yoff, v);
+        if (csum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = (p.out_f32 ? v[e] : stored_value<HT>(v[e])) - csh[e]; cs[e] += d; cq[e] += d * d; }
+        }
       } else if (!VEC) {
         // unaligned / ragged channel tail (e.g. the nc-channel class conv, the 66-wide detect map)
         const int lim = (p.out_mode == MTBT_OUT_CONVT2X2) ? (ch / (p.K >> 2) + 1) * (p.K >> 2) : p.K;
-        for (int e = 0; e < 8 && ch + e < lim; ++e) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (ch + e >= lim) break;
           float u = v[e];
           if (TRAIN && p.y2) {
             if (p.out_f32) reinterpret_cast<float*>(p.y2)[yoff + e] = u;
@@ -113,10 +153,14 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
           }
           if (p.out_f32) reinterpret_cast<float*>(p.y)[yoff + e] = u;
           else st_elem<HT>(reinterpret_cast<HT*>(p.y) + yoff + e, u);
+          if (csum) { const float d = (p.out_f32 ? u : stored_value<HT>(u)) - csh[e]; cs[e] += d; cq[e] += d * d; }   // (e: compile-time after unrolling)
         }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
+  }
+  if constexpr (CS_OK) {
+    if (csum) colsum_flush<C8>(p, cs, cq, srow, cs_ch, cs_ch < p.K && (lane % C8) < C8, lane);
   }
 }
 
@@ -129,9 +173,9 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
 // MODE 0: y = act(affine) (+ res);  1: y2 = affine (pre-activation), y = act(affine) (+ res);  2: y = affine * act'(res)  (ACT = MTBT_ACT_D*)
 struct EpiSeq { long pix0; int jstep; long npix; long ybias, rbias; };
 
-template <typename T, int TC, int FC, int FP, int ACT, int MODE>
+template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase, int chl0, int lane,
-                                                   const EpiSeq q) {
+                                                   const EpiSeq q, long srow = -1) {
   constexpr int WCH = FC * 16;
   constexpr int PITCH = WCH * 4 + 16;
   constexpr int C8 = WCH / 8;
@@ -164,6 +208,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
   }
   const long ystep = (long)q.jstep * p.ldy, rstep = (long)q.jstep * p.ldr;
   const bool has_res = p.res != nullptr;
+  const int cs_ch = cbase + chl0 + (lane % C8) * 8;     // column sums (SUMS): see colsum_flush
+  float cs[8], cq[8], csh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; csh[e] = (SUMS && p.cs_shift && cs_ch + e < p.K) ? p.cs_shift[cs_ch + e] : 0.f; }
   HT* const yp = reinterpret_cast<HT*>(p.y);
   HT* const y2p = reinterpret_cast<HT*>(p.y2);
   const T* const rp = reinterpret_cast<const T*>(p.res);
@@ -209,18 +257,28 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
         for (int e = 0; e < 8; ++e) v[e] += r[e];
       }
       st8<HT>(yp + yoff, v);
+      if (SUMS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = stored_value<HT>(v[e]) - csh[e]; cs[e] += d; cq[e] += d * d; }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
   }
+  if constexpr (SUMS && (C8 & (C8 - 1)) == 0) colsum_flush<C8>(p, cs, cq, srow, cs_ch, cs_ch < p.K, lane);
 }
 
 // Dispatcher: ONE switch per call.  `seq` non-null = the caller's output pixels form the arithmetic sequence the fast body wants.
 template <typename T, int TC, int FC, int FP, bool TRAIN = true, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
-                                              int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq* seq = nullptr) {
+                                              int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq* seq = nullptr,
+                                              long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {
 #define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV>(p, acc, slab, aff, cbase, chl0, lane, *seq)
   const bool fast = seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
-  if (fast && !(TRAIN && p.y2)) {
+  constexpr bool CS_OK = (((FC * 16) / 8) & ((FC * 16) / 8 - 1)) == 0;
+  if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
+    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true>(p, acc, slab, aff, cbase, chl0, lane, *seq, srow); return; }
+    if (TRAIN && p.act == MTBT_ACT_DGELU) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU, 2, true>(p, acc, slab, aff, cbase, chl0, lane, *seq, srow); return; }
+  } else if (fast && !(TRAIN && p.y2)) {
     switch (p.act) {
       case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;
       case MTBT_ACT_SILU: MTBT_FAST(MTBT_ACT_SILU, 0); return;
@@ -242,7 +300,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
   }
 #undef MTBT_FAST
   // everything else (fp32 / ragged / transposed-conv outputs, rare activation + mode pairs): the general body, run-time activation
-  conv_epilogue_body<T, TC, FC, FP, TRAIN, -1, false>(p, acc, slab, aff, cbase, chl0, lane, addr);
+  conv_epilogue_body<T, TC, FC, FP, TRAIN, -1, false>(p, acc, slab, aff, cbase, chl0, lane, addr, srow);
 }
 
 }  // namespace

@@ -2,6 +2,7 @@
 // dispatch to the per-dtype translation units (conv_igemm_bf16.hip, conv_igemm_f32.hip; kernel in conv_igemm.inc).
 #include "common.h"
 #include "conv_params.h"
+#include "rowreduce.h"
 
 int mtbt_conv_dispatch_bf16(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
 int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
@@ -17,13 +18,13 @@ int mtbt_conv3x3_direct_f16(const ConvP& p, int TC, hipStream_t s);
 //     -> 32 KiB of LDS, three or more workgroups per CU hide the load / epilogue latency of the short K loop;
 //   * k x k convolutions (MFMA-bound): 128-pixel tiles with 128-byte K-steps while that still gives >= 2
 //     workgroups per CU, else 64x64 (small pyramid levels, 64-channel head convs).
-static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow) {
+static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow, bool no96 = false) {
   // pol (mtbt_conv_args.policy, a development A/B knob the host passes per call): bit0 = small 1x1 tiles, bit1 = 64x64 for small k x k
   int tc;
   if (K % 128 == 0) tc = 128;
-  else if (K % 96 == 0) tc = 96;
-  else if (K > 96) tc = 128;
-  else if (K > 64) tc = 96;
+  else if (K % 96 == 0 && !no96) tc = 96;
+  else if (K > 96) tc = (no96 && K % 64 == 0) ? 64 : 128;
+  else if (K > 64) tc = no96 ? 128 : 96;
   else if (K > 32) tc = 64;
   else tc = 32;
   const long ct = (K + tc - 1) / tc;
@@ -47,6 +48,7 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
   if (((M + 63) / 64) * ct >= 256) { *TC = tc; *TP = 64; return; }
   *TC = (tc == 96) ? 96 : 64;
   *TP = 64;
+  if (no96 && *TC == 96) *TC = 64;
 }
 
 // LDS stages: as deep as fits 64 KiB (two workgroups per CU stay resident), at least 2, no deeper than the K loop.
@@ -61,7 +63,23 @@ static int pick_nbuf(int TC, int TP, int BKB, int nsteps) {
   return n;
 }
 
-extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
+extern "C" int64_t mtbt_conv_colsum_workspace_bytes(int64_t pixels, int K, int with_squares) {
+  if (pixels <= 0 || K <= 0) return 0;
+  return (pixels / 64 + 1) * 4 * (int64_t)K * (with_squares ? 2 : 1) * (int64_t)sizeof(float);   // <= 4 partial rows per 64 pixels
+}
+
+// second level of the column sums: `rows` partial rows -> colsum (one wave per channel, fixed order)
+static int colsum_finish(const mtbt_conv_args* a, const ConvP& p, long rows, hipStream_t s) {
+  if (rows <= 0 || rows > 0x7fffffffL) return MTBT_EINVAL;
+  hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((a->K + 3) / 4)), dim3(256), 0, s, p.cs_part, (int)rows, p.cs_pitch, 0, a->K, a->colsum, a->colsum_accumulate);
+  if (a->colsum_sq)
+    hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((a->K + 3) / 4)), dim3(256), 0, s, p.cs_part, (int)rows, p.cs_pitch, a->K, a->K, a->colsum + a->K, a->colsum_accumulate);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+// `layout` non-null: validate and choose the kernel as a launch would, report the column-sum partial layout, launch nothing.
+static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [2]: rows, pitch */) {
   if (!a || !a->x || !a->w || !a->y) return MTBT_EINVAL;
   if (a->dtype != MTBT_F32 && a->dtype != MTBT_BF16 && a->dtype != MTBT_F16) return MTBT_EINVAL;
   if (a->out_dtype != a->dtype && a->out_dtype != MTBT_F32) return MTBT_EINVAL;
@@ -93,6 +111,14 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
   p.ctiles = 0;
   p.ptiles_per_xcd = 0;
   p.debug = a->debug;
+  // column sums (header): partial rows in the caller's workspace, second level after the conv
+  p.cs_part = nullptr; p.cs_shift = a->colsum_shift; p.cs_sq = a->colsum_sq ? 1 : 0; p.cs_pitch = a->K * (a->colsum_sq ? 2 : 1);
+  const bool want_cs = a->colsum_ws != nullptr;      // partial rows (and, with colsum, the finished sums)
+  if (a->colsum && !want_cs) return MTBT_EINVAL;
+  if (want_cs) {
+    if (a->out_mode != MTBT_OUT_NHWC || !aligned16(a->colsum_ws)) return MTBT_EINVAL;
+    p.cs_part = reinterpret_cast<float*>(a->colsum_ws);
+  }
   const int pol = (a->policy & 0x100) ? (a->policy & 0xff) : 7;   // 0 = the default policy
   // LDS-DMA addressing: 32-bit byte offsets below 2 GiB relative to (first image of a tile, weight tile row 0)
   if ((double)a->R * a->S > 31) return MTBT_EINVAL;
@@ -119,16 +145,41 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) {
       // row-reuse variant (conv3x3_rr_kernel): the default for 64-channel tiles (head convs, 6 % faster there; policy bit 4
       // turns that off), everywhere with policy bit 3 / hint bit 25
       if ((pol & 8) || ((a->tile_hint >> 25) & 1) || (tc == 64 && !(pol & 16))) tc |= 0x1000;
-      return a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : (a->dtype == MTBT_F16 ? mtbt_conv3x3_direct_f16(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s));
+      const long rows = (long)a->N * (a->H >> 4) * (a->W >> 4) * ((tc & 0x1000) ? 2 : 4);   // partial rows per 16x16 tile: see conv3x3_direct.inc
+      if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; return MTBT_OK; }
+      if (want_cs && a->colsum_ws_bytes < rows * p.cs_pitch * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+      const int rc = a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : (a->dtype == MTBT_F16 ? mtbt_conv3x3_direct_f16(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s));
+      if (rc != MTBT_OK || !a->colsum) return rc;
+      return colsum_finish(a, p, rows, s);
     }
   }
   int TC, TP, nbuf = 0;
   if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x1ff; TP = a->tile_hint & 0xffff; }
   int narrow = (a->tile_hint >> 27) & 1;  // hint bit 27: force 64-byte K-steps
-  if (!a->tile_hint || !TC || !TP) pick_tile(pol, a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow);
+  if (!a->tile_hint || !TC || !TP) pick_tile(pol, a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow, want_cs);
+  if (want_cs && TC == 96) return MTBT_EINVAL;   // (a wave's 48 / 96 channels are not a power-of-two number of 8-channel pieces)
   const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));
-  if (a->dtype == MTBT_F32) return mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s);
-  if (a->dtype == MTBT_F16) return mtbt_conv_dispatch_f16(p, TC, TP, wide, nbuf, s);
-  return mtbt_conv_dispatch_bf16(p, TC, TP, wide, nbuf, s);
+  const int waves_p = (TC == 128 || (TC == 96 && TP == 64)) ? 2 : 4;    // wave layouts of conv_igemm.inc's dispatch_tile
+  const long rows = (((long)p.M + TP - 1) / TP) * waves_p;
+  if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; return MTBT_OK; }
+  if (want_cs && a->colsum_ws_bytes < rows * p.cs_pitch * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
+  const int rc = a->dtype == MTBT_F32 ? mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s)
+                                      : (a->dtype == MTBT_F16 ? mtbt_conv_dispatch_f16(p, TC, TP, wide, nbuf, s) : mtbt_conv_dispatch_bf16(p, TC, TP, wide, nbuf, s));
+  if (rc != MTBT_OK || !a->colsum) return rc;
+  return colsum_finish(a, p, rows, s);
+}
+
+extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) { return conv_impl(a, stream, nullptr); }
+
+// The partial rows a call with these arguments writes into colsum_ws: rows x pitch floats, row r = [sum (K) | sum of squares (K, with
+// colsum_sq)] of one (pixel tile, wave row); rows that cover no pixel hold zeros.  For a consumer that reduces them itself
+// (mtbt_bn_forward_partials_nhwc) instead of asking for the finished sums.
+extern "C" int mtbt_conv_colsum_layout(const mtbt_conv_args* a, int64_t* rows, int32_t* pitch) {
+  if (!rows || !pitch || !a || !a->colsum_ws) return MTBT_EINVAL;
+  int64_t lay[2] = {0, 0};
+  const int rc = conv_impl(a, nullptr, lay);
+  if (rc != MTBT_OK) return rc;
+  *rows = lay[0]; *pitch = (int32_t)lay[1];
+  return MTBT_OK;
 }

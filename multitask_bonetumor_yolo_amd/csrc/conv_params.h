@@ -17,5 +17,10 @@ struct ConvP {
   int M;       // N*Ho*Wo (< 2^31)
   int ctiles;  // ceil(K / TC)
   int ptiles_per_xcd;  // ceil(ceil(M / TP) / 8)
+  // optional per-channel column sums of the STORED output (bias gradients, BatchNorm batch statistics): partial rows [rows][cs_pitch]
+  // of sum (v - cs_shift[k]) in [0, K) and, with cs_sq, of its square in [K, 2K); one row per (pixel tile, wave row), see conv_epilogue.h
+  float* cs_part;
+  const float* cs_shift;
+  int cs_sq, cs_pitch;
   int debug;  // development ablation bits (MTBT_CONV_DEBUG): 1 = no DMA in the K loop, 2 = no fragment reads / MFMAs
 };

@@ -19,6 +19,8 @@ order) in the kernels' layouts; 4-D conv weights are channels-last there, so the
 import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -26,6 +28,9 @@ from . import _lib as L
 from . import model as M
 from .dist_train import FlatBuckets
 from .engine import Act, ESIZE, Launch, Plan, TORCH_DTYPE, _region
+
+# column sums from the conv epilogue (BatchNorm batch statistics, d fc1.bias) instead of separate passes; MTBT_FUSED_COLSUM=0 turns them off (A/B)
+FUSED_BN_STATS = os.environ.get("MTBT_FUSED_COLSUM", "1") != "0"
 
 WS_BYTES = 256 << 20           # shared scratch of the reduction kernels (sequential plan)
 CLS_PAD = 32                   # the nc-channel class conv's gradient operand is zero-padded to this many channels
@@ -106,21 +111,61 @@ class TPlan(Plan):
         l = self.launches[-1]
         l.bytes, l.flops = max(l.bytes, nbytes), max(l.flops, flops)
 
-    def conv2(self, x: Act, w, y: Act, *, y2: Optional[Act] = None, **kw):
+    def conv2(self, x: Act, w, y: Act, *, y2: Optional[Act] = None, colsum: Optional[torch.Tensor] = None, colsum_sq=False,
+              colsum_shift: Optional[torch.Tensor] = None, **kw):
+        """`colsum` [K] / [2K] fp32: per-channel sums (and sums of squares) of the stored output minus `colsum_shift`, from the conv epilogue."""
         a = self.conv(x, w, y, **kw)
+        l = self.launches[-1]
         if y2 is not None:
             assert y2.ld == y.ld and y2.bs == y.bs and y2.code == y.code
             a.y2 = y2.ptr
-            l = self.launches[-1]
             l.keep = l.keep + (y2.buf,)
             l.writes = l.writes + (_region(y2),)
+        if colsum is not None:
+            K = w.shape[0]
+            partial_only = colsum is True      # the consumer reduces the partial rows itself (BatchNorm): see colsum_partials()
+            assert K % 8 == 0 and (partial_only or (colsum.dtype == torch.float32 and colsum.numel() == K * (2 if colsum_sq else 1)))
+            nbytes = self.lib.mtbt_conv_colsum_workspace_bytes(a.N * a.Ho * a.Wo, K, int(colsum_sq))
+            a.colsum, a.colsum_sq, a.colsum_accumulate = (None if partial_only else colsum.data_ptr()), int(colsum_sq), 0
+            a.colsum_shift = colsum_shift.data_ptr() if colsum_shift is not None else None
+            if partial_only:                   # the partial rows outlive the launch: a buffer of their own (exact size), not the rotating scratch
+                a.colsum_ws, a.colsum_ws_bytes = 16, nbytes          # (placeholder for the layout query)
+                rows, pitch = C.c_int64(0), C.c_int32(0)
+                L.check(self.lib.mtbt_conv_colsum_layout(C.byref(a), C.byref(rows), C.byref(pitch)), "colsum layout")
+                nbytes = rows.value * pitch.value * 4
+                self.cs_partial = torch.empty(rows.value * pitch.value, dtype=torch.float32, device=self.device)
+                a.colsum_ws = self.cs_partial.data_ptr()
+                self.cs_layout = (self.cs_partial, rows.value, pitch.value)
+            else:
+                a.colsum_ws = self._ws(nbytes)
+                self.cs_partial = self.cur_ws
+            a.colsum_ws_bytes = nbytes
+            l.keep = l.keep + (colsum if not partial_only else None, colsum_shift, self.cs_partial)
+            l.writes = l.writes + ((_region(colsum),) if not partial_only else ()) + (_region(self.cs_partial),)
+            if colsum_shift is not None:
+                l.reads = l.reads + (_region(colsum_shift),)
         return a
 
-    def bn_forward(self, x: Act, y: Act, bn, act, stats: torch.Tensor, use_running: bool, name):
+    @staticmethod
+    def colsum_ok(K: int) -> bool:
+        """The conv epilogue can accumulate column sums for this output width (tile choices: conv_igemm.hip pick_tile with no96)."""
+        return K % 8 == 0 and not (64 < K <= 96)
+
+    def bn_forward(self, x: Act, y: Act, bn, act, stats: torch.Tensor, use_running: bool, name, sums: Optional[torch.Tensor] = None):
+        """`sums` [2C]: column sums of x - running_mean and their squares, accumulated by the conv that produced x (one pass saved)."""
         assert x.dense and x.C == y.C and x.code == y.code and y.bs == y.H * y.W * y.ld
         if bn.momentum is None:
             raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not supported")
         pixels = x.N * x.H * x.W
+        if sums is not None and not use_running:
+            part, rows, pitch = sums          # (partial rows of the producing conv, mtbt_conv_colsum_layout)
+            g, b = _dense_vec(bn.weight, name + ".weight"), _dense_vec(bn.bias, name + ".bias")
+            args = (x.ptr, y.ptr, y.ld, g.data_ptr(), b.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C.c_float(bn.momentum),
+                    C.c_float(bn.eps), act, pixels, x.C, x.code, part.data_ptr(), rows, pitch, bn.running_mean.data_ptr(), stats.data_ptr())
+            self.raw(self.lib.mtbt_bn_forward_partials_nhwc, args, name, keep=(x.buf, y.buf, stats, bn, part), reads=[x, part],
+                     writes=[y, stats, bn.running_mean, bn.running_var])
+            self.est(2.0 * pixels * x.C * ESIZE[x.code])
+            return
         nbytes = self.lib.mtbt_bn_train_workspace_bytes(pixels, x.C)
         g, b = _dense_vec(bn.weight, name + ".weight"), _dense_vec(bn.bias, name + ".bias")
         args = (x.ptr, y.ptr, y.ld, g.data_ptr(), b.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), C.c_float(bn.momentum),
@@ -451,14 +496,20 @@ class TrainPlan:
         wf, wd = self.w_fwd(conv.weight), self.w_dgrad(conv.weight)
         raw = self.new(x.N, x.H, x.W, K)
         bias = _dense_vec(conv.bias, name + ".bias") if conv.bias is not None else None
-        self.fwd.conv(x, wf, raw, R=k, S=k, stride=1, pad=k // 2, shift=bias, name=name)
+        running = not bn.training
+        # batch statistics: the conv's own epilogue accumulates sum / sum of squares of what it stores (about the running mean)
+        sums = None
+        if not running and self.fwd.colsum_ok(K) and FUSED_BN_STATS:
+            self.fwd.conv2(x, wf, raw, R=k, S=k, stride=1, pad=k // 2, shift=bias, name=name, colsum=True, colsum_sq=True, colsum_shift=bn.running_mean)
+            sums = self.fwd.cs_layout
+        else:
+            self.fwd.conv(x, wf, raw, R=k, S=k, stride=1, pad=k // 2, shift=bias, name=name)
         if y is None:
             y = self.new(x.N, x.H, x.W, K)
         st = self.stats(K)
-        running = not bn.training
         if not running:
             self.train_bns.append(bn)
-        self.fwd.bn_forward(raw, y, bn, act, st, running, name + ".bn")
+        self.fwd.bn_forward(raw, y, bn, act, st, running, name + ".bn", sums=sums)
 
         def bwd():
             if not self.has_grad(y):
@@ -549,12 +600,17 @@ class TrainPlan:
         wd = self.prep_w(pw, (Cc, 1, 1, K), (pw.stride(1), 0, 0, pw.stride(0)), scale0=(vec, 0)).view(Cc, K)
         bn = mod.bn
         raw, y = self.new(x.N, x.H, x.W, K), self.new(x.N, x.H, x.W, K)
-        self.fwd.conv(x, wf, raw, name=name)
-        st = self.stats(K)
         running = not bn.training
+        sums = None
+        if not running and self.fwd.colsum_ok(K) and FUSED_BN_STATS:
+            self.fwd.conv2(x, wf, raw, name=name, colsum=True, colsum_sq=True, colsum_shift=bn.running_mean)
+            sums = self.fwd.cs_layout
+        else:
+            self.fwd.conv(x, wf, raw, name=name)
+        st = self.stats(K)
         if not running:
             self.train_bns.append(bn)
-        self.fwd.bn_forward(raw, y, bn, L.ACT_ELU, st, running, name + ".bn")
+        self.fwd.bn_forward(raw, y, bn, L.ACT_ELU, st, running, name + ".bn", sums=sums)
         gtmp = torch.empty(K, Cc, dtype=torch.float32, device=self.device)
 
         def bwd():
@@ -677,9 +733,12 @@ class TrainPlan:
                                                     dW2.data_ptr(), dg.data_ptr(), db2.data_ptr(), d, 4 * d, 0), name + ".fc2.scale_grad",
                          keep=(gtmp, ssum, dW2, dg, db2), reads=[gtmp, ssum], writes=[dW2, dg, db2])
             d_hpre = self.bwd.new(N, H, W, 4 * d, T)
-            self.bwd.conv2(dy, w2d, d_hpre, act=L.ACT_DGELU, res=hpre, name=name + ".fc2.dgrad*gelu'")
+            # (d fc1.bias = sum_p d_hpre comes out of the same launch: column sums in the epilogue instead of a pass over the 4d-wide tensor)
+            fused_db = self.bwd.colsum_ok(4 * d) and FUSED_BN_STATS
+            self.bwd.conv2(dy, w2d, d_hpre, act=L.ACT_DGELU, res=hpre, name=name + ".fc2.dgrad*gelu'", colsum=self.pg(fc1.bias).view(-1) if fused_db else None)
             self.bwd.wgrad(t, d_hpre, self.pg(fc1.weight), R=1, S=1, pad=0, name=name + ".fc1.wgrad")
-            self.bwd.channel_sum(d_hpre, self.pg(fc1.bias), name=name + ".fc1.dbias")
+            if not fused_db:
+                self.bwd.channel_sum(d_hpre, self.pg(fc1.bias), name=name + ".fc1.dbias")
             d_t = self.bwd.new(N, H, W, d, T)
             self.bwd.conv2(d_hpre, w1d, d_t, name=name + ".fc1.dgrad")
             self.bwd.release(d_hpre)

@@ -280,6 +280,14 @@ def test_training_plans_on_lanes_are_bit_identical(monkeypatch):
     gt_masks[:, 0, 60:140, 50:170] = 1
     gt_cls = torch.tensor([0, 1, 1, 0]).to(DEV)
     ts = TrainStep(hip, (B, 3, S, S), optimizer="sgd", lr=0.0, iou_match_thresh=0.05)     # lr 0: the weights stay put between the runs
+    # the BatchNorm running statistics are part of the state a step reads (the conv epilogue accumulates its column sums about the running
+    # mean): every run starts from the same copy
+    bufs = {n: b.clone() for n, b in hip.named_buffers()}
+
+    def reset():
+        with torch.no_grad():
+            for n, b in hip.named_buffers():
+                b.copy_(bufs[n])
     monkeypatch.setenv("MTBT_TRAIN_LANES", "0")
     ts.forward_backward(x, gt_boxes, gt_masks, gt_cls)
     torch.cuda.synchronize()
@@ -287,6 +295,7 @@ def test_training_plans_on_lanes_are_bit_identical(monkeypatch):
     monkeypatch.setenv("MTBT_TRAIN_LANES", "1")
     monkeypatch.setenv("MTBT_LANES", "4")
     for _ in range(6):
+        reset()
         ts.forward_backward(x, gt_boxes, gt_masks, gt_cls)
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(zip(ref, ts.grads.buckets)):

@@ -515,3 +515,94 @@ def test_layernorm_backward_with_parameter_gradients(dtype, Cc):
     close(dx.float().cpu() - prev.float(), x.grad, tol, "dx")
     close(dg, gam.grad, tol, "dgamma")
     close(db, bet.grad, tol, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    # (N, H, W, C, K, k, act, residual-as-GELU'-input)
+    (2, 9, 7, 64, 128, 1, 0, False),      # implicit GEMM 1x1, 128-channel tile, ragged pixel tile
+    (2, 16, 16, 64, 64, 3, 0, False),     # direct 3x3 (row-reuse kernel for 64-channel tiles in 16-bit modes)
+    (1, 32, 32, 128, 256, 3, 0, False),   # direct 3x3, two channel tiles
+    (2, 10, 10, 64, 192, 3, 0, False),    # 3x3 on the implicit-GEMM kernel (map not 16-aligned); K = 192 must avoid the 96-channel tile
+    (3, 8, 8, 96, 384, 1, 7, True),       # fc2-dgrad * GELU'(pre-activation): d fc1.bias from the same launch
+    (1, 5, 5, 64, 32, 1, 0, False),       # 32-channel tile
+])
+def test_conv_column_sums(dtype, cfg):
+    """mtbt_conv_args.colsum: per-channel sums (and sums of squares about a shift) of the STORED conv output, from the epilogue --
+    against the same sums taken over the output tensor the call wrote; then BatchNorm statistics from them against torch."""
+    N, H, W, Cc, K, k, act, deriv = cfg
+    lib = L.load()
+    torch.manual_seed(21)
+    x = torch.randn(N, Cc, H, W).to(dtype).float()
+    w = (torch.randn(K, Cc, k, k) / (Cc * k * k) ** 0.5).to(dtype).float()
+    b = torch.randn(K) * 0.3 + 0.5
+    shift = torch.randn(K) * 0.1 + 0.4
+    p = Plan(torch.device(DEV))
+    xa = Act.of(nhwc(x, dtype))
+    y = Act.of(torch.empty(N, H, W, K, dtype=dtype, device=DEV))
+    wp = w.permute(0, 2, 3, 1).reshape(K, -1).contiguous().to(DEV, dtype)
+    res = Act.of(nhwc(torch.randn(N, K, H, W), dtype)) if deriv else None
+    a = p.conv(xa, wp, y, R=k, S=k, pad=k // 2, shift=b.to(DEV), act=act, res=res)
+    sums = torch.full((2 * K,), 7.0, device=DEV)
+    sh = shift.to(DEV)
+    nb = lib.mtbt_conv_colsum_workspace_bytes(N * H * W, K, 1)
+    ws = torch.empty(nb // 4 + 4, device=DEV)
+    a.colsum, a.colsum_shift, a.colsum_sq, a.colsum_accumulate = sums.data_ptr(), sh.data_ptr(), 1, 0
+    a.colsum_ws, a.colsum_ws_bytes = ws.data_ptr(), nb
+    p.run()
+    torch.cuda.synchronize()
+    stored = y.buf.float().cpu().reshape(-1, K).double()
+    want1 = (stored - shift.double()).sum(0)
+    want2 = ((stored - shift.double()) ** 2).sum(0)
+    got = sums.cpu().double()
+    tol = 2e-5 if dtype == torch.float32 else 2e-4        # (fp32 accumulation order only: the summed values are the stored ones)
+    assert (got[:K] - want1).abs().max() <= tol * (stored - shift.double()).abs().sum(0).max() + 1e-6
+    assert (got[K:] - want2).abs().max() <= tol * want2.max() + 1e-6
+    # accumulate form, sums only
+    a.colsum_sq, a.colsum_accumulate = 0, 1
+    p.run()
+    torch.cuda.synchronize()
+    assert (sums.cpu().double()[:K] - 2 * want1).abs().max() <= 2 * tol * (stored - shift.double()).abs().sum(0).max() + 1e-6
+    if act != 0:
+        return
+    # BatchNorm forward from the sums == BatchNorm forward with its own statistics pass
+    a.colsum_sq, a.colsum_accumulate = 1, 0
+    p.run()
+    bn = torch.nn.BatchNorm2d(K, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2); bn.running_mean.copy_(shift); bn.running_var.uniform_(0.5, 1.5)
+    rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+    g, be = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    out = torch.empty_like(y.buf)
+    stats = torch.empty(2 * K, device=DEV)
+    pixels = N * H * W
+    L.check(lib.mtbt_bn_forward_sums_nhwc(y.ptr, out.data_ptr(), K, g.data_ptr(), be.data_ptr(), rm.data_ptr(), rv.data_ptr(), C.c_float(0.03), C.c_float(1e-3),
+                                          L.ACT_SILU, pixels, K, CODE[dtype], sums.data_ptr(), rm.data_ptr(), stats.data_ptr(), S()), "bn from sums")
+    torch.cuda.synchronize()
+    ref_in = y.buf.float().cpu().permute(0, 3, 1, 2)
+    bn.train()
+    ref = F.silu(bn(ref_in))
+    close(back(out), ref.detach(), 2e-5 if dtype == torch.float32 else 2e-2, "bn(y) from column sums")
+    close(stats[:K], ref_in.mean((0, 2, 3)), 2e-5, "batch mean")
+    close(stats[K:], ref_in.var((0, 2, 3), unbiased=False), 1e-4, "batch variance")
+    close(rm, bn.running_mean, 2e-5, "running mean"); close(rv, bn.running_var, 1e-4, "running var")
+    # the consumer form: only the partial rows are written (layout from mtbt_conv_colsum_layout), BatchNorm reduces them itself
+    rows, pitch = C.c_int64(0), C.c_int32(0)
+    a.colsum = None
+    L.check(lib.mtbt_conv_colsum_layout(C.byref(a), C.byref(rows), C.byref(pitch)), "layout")
+    assert pitch.value == 2 * K and 0 < rows.value * pitch.value * 4 <= nb
+    part = torch.full((rows.value * pitch.value,), float("nan"), device=DEV)
+    a.colsum_ws, a.colsum_ws_bytes = part.data_ptr(), part.numel() * 4
+    p.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all(), "every partial row the layout announces is written"
+    rm2, rv2 = shift.clone().to(DEV), bn.running_var.clone().to(DEV)
+    out2, stats2 = torch.empty_like(out), torch.empty_like(stats)
+    L.check(lib.mtbt_bn_forward_partials_nhwc(y.ptr, out2.data_ptr(), K, g.data_ptr(), be.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), C.c_float(0.03),
+                                              C.c_float(1e-3), L.ACT_SILU, pixels, K, CODE[dtype], part.data_ptr(), rows.value, pitch.value, rm2.data_ptr(),
+                                              stats2.data_ptr(), S()), "bn from partial rows")
+    torch.cuda.synchronize()
+    close(stats2, stats.cpu(), 1e-5, "statistics from the partial rows == from the finished sums")
+    assert torch.equal(out2, out) or (out2.float() - out.float()).abs().max().item() <= 2e-2
+    a.colsum_ws_bytes = part.numel() * 4 - 4
+    assert lib.mtbt_conv2d_nhwc(C.byref(a), S()) == -4, "a partial buffer smaller than the layout is refused (MTBT_EWORKSPACE)"
