@@ -273,8 +273,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq* seq = nullptr,
                                               long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {
 #define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV>(p, acc, slab, aff, cbase, chl0, lane, *seq)
-  const bool fast = seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
+  // (fp32 storage always writes fp32: the fast bodies -- 16-bit outputs -- are not even compiled for it)
+  const bool fast = sizeof(T) == 2 && seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
   constexpr bool CS_OK = (((FC * 16) / 8) & ((FC * 16) / 8 - 1)) == 0;
+  if constexpr (sizeof(T) == 2) {
   if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
     if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true>(p, acc, slab, aff, cbase, chl0, lane, *seq, srow); return; }
     if (TRAIN && p.act == MTBT_ACT_DGELU) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU, 2, true>(p, acc, slab, aff, cbase, chl0, lane, *seq, srow); return; }
@@ -297,6 +299,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       case MTBT_ACT_GELU_POLY: MTBT_FAST(MTBT_ACT_GELU_POLY, 1); return;
       default: break;
     }
+  }
   }
 #undef MTBT_FAST
   // everything else (fp32 / ragged / transposed-conv outputs, rare activation + mode pairs): the general body, run-time activation

@@ -4,12 +4,19 @@
 #include "conv_params.h"
 #include "rowreduce.h"
 
-int mtbt_conv_dispatch_bf16(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
-int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
-int mtbt_conv3x3_direct_bf16(const ConvP& p, int TC, hipStream_t s);
-int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s);
-int mtbt_conv_dispatch_f16(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s);
-int mtbt_conv3x3_direct_f16(const ConvP& p, int TC, hipStream_t s);
+// per (storage type, K-step width) translation units; two LDS stages (deeper pipelines never paid: residency beats prefetch depth)
+#define MTBT_DECL(dt)                                                                      \
+  int mtbt_conv_dispatch_##dt##_wide(const ConvP& p, int TC, int TP, hipStream_t s);       \
+  int mtbt_conv_dispatch_##dt##_narrow(const ConvP& p, int TC, int TP, hipStream_t s);     \
+  int mtbt_conv3x3_direct_##dt(const ConvP& p, int TC, hipStream_t s);                     \
+  static int mtbt_conv_dispatch_##dt(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s) { \
+    (void)nbuf;                                                                            \
+    return wide ? mtbt_conv_dispatch_##dt##_wide(p, TC, TP, s) : mtbt_conv_dispatch_##dt##_narrow(p, TC, TP, s); \
+  }
+MTBT_DECL(bf16)
+MTBT_DECL(f32)
+MTBT_DECL(f16)
+#undef MTBT_DECL
 
 // Tile heuristics, from the sweep in tools/conv_tune.py on the shapes of the 640x640 batch-16 forward
 // (numbers in DESIGN.md):

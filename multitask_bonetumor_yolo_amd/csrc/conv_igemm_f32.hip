@@ -1,16 +1,5 @@
-// fp32 (exact-fp32 MFMA, parity mode) instantiations of the implicit-GEMM conv (see conv_igemm.inc).
+// fp32 (exact-fp32 MFMA, parity mode) instantiations of the implicit-GEMM conv, 128-byte K-steps (kernel in conv_igemm.inc).  One translation unit per (storage type,
+// K-step width) and one for the direct 3x3 kernels: the build compiles them in parallel.
 #include "conv_igemm.inc"
-#include "conv3x3_direct.inc"
 
-int mtbt_conv_dispatch_f32(const ConvP& p, int TC, int TP, int wide, int nbuf, hipStream_t s) {
-  (void)nbuf;
-  return wide ? dispatch_tile<float, 128, 2>(p, TC, TP, s) : dispatch_tile<float, 64, 2>(p, TC, TP, s);
-}
-
-int mtbt_conv3x3_direct_f32(const ConvP& p, int TC, hipStream_t s) {
-  if (TC == (128 | 0x1000)) return launch_direct3x3_rr<float, 128>(p, s);
-  if (TC == (64 | 0x1000)) return launch_direct3x3_rr<float, 64>(p, s);
-  if (TC == 128) return launch_direct3x3<float, 128>(p, s);
-  if (TC == 64) return launch_direct3x3<float, 64>(p, s);
-  return MTBT_EINVAL;
-}
+int mtbt_conv_dispatch_f32_wide(const ConvP& p, int TC, int TP, hipStream_t s) { return dispatch_tile<float, 128, 2>(p, TC, TP, s); }

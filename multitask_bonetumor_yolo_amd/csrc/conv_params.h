@@ -24,3 +24,11 @@ struct ConvP {
   int cs_sq, cs_pitch;
   int debug;  // development ablation bits (MTBT_CONV_DEBUG): 1 = no DMA in the K loop, 2 = no fragment reads / MFMAs
 };
+
+// Development ablation bits (MTBT_CONV_DEBUG) are compiled in only with -DMTBT_CONV_ABLATION: run-time tests
+// inside the K loop split it into dozens of basic blocks and keep the scheduler from batching the fragment reads.
+#ifdef MTBT_CONV_ABLATION
+#define MTBT_ABL(p, bit) ((p).debug & (bit))
+#else
+#define MTBT_ABL(p, bit) 0
+#endif
