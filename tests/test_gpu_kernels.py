@@ -160,7 +160,8 @@ def test_stem(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 96, 9, 11), (1, 192, 8, 8), (1, 768, 5, 6), (1, 384, 4, 4), (1, 96, 20, 37), (2, 384, 17, 16)])
+@pytest.mark.parametrize("shape", [(2, 96, 9, 11), (1, 192, 8, 8), (1, 768, 5, 6), (1, 384, 4, 4), (1, 96, 20, 37), (2, 384, 17, 16),
+                                   (1, 384, 40, 40), (2, 384, 12, 20), (1, 768, 20, 24), (1, 192, 16, 32)])   # whole half-width / full tiles (no bounds branches)
 def test_dwconv7_layernorm(dtype, shape):
     N, Cc, H, W = shape
     g = torch.Generator().manual_seed(6)
@@ -198,6 +199,28 @@ def test_dwconv3_affine_silu(dtype):
     p = Plan(torch.device(DEV))
     ya = Act.of(torch.zeros(N, H, W, Cc, dtype=dtype, device=DEV))
     p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 9).t().contiguous().to(DEV, dtype), ya, 3, scale=sc.to(DEV), shift=sh.to(DEV), act=1)
+    run(p)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert (back(ya.buf) - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 384, 12, 20), (1, 768, 8, 24), (1, 192, 16, 16), (2, 96, 9, 11), (1, 256, 40, 40)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_dwconv7_affine_wide(dtype, shape, act):
+    """The scale / shift form of the 7x7 kernel (depthwise dgrad): wider tensors run the one-chunk kernel with the 128-channel chunks as
+    grid rows; half-width tiles when the width is not a whole number of 16-pixel tiles; activation constants and the run-time form."""
+    N, Cc, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w = torch.randn(Cc, 1, 7, 7, generator=g) / 7
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    ref = ACTS[act](F.conv2d(x, w, None, 1, 3, groups=Cc) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    p = Plan(torch.device(DEV))
+    ya = Act.of(torch.zeros(N, H, W, Cc, dtype=dtype, device=DEV))
+    p.dwconv(Act.of(nhwc(x).to(dtype)), w.reshape(Cc, 49).t().contiguous().to(DEV, dtype), ya, 7, scale=sc.to(DEV), shift=sh.to(DEV), act=act)
     run(p)
     tol = TOL32 if dtype == torch.float32 else 3e-2
     assert (back(ya.buf) - ref).abs().max().item() < tol
