@@ -50,15 +50,15 @@ for (N, H, Cc) in [(16, 40, 384), (32, 40, 384)]:
 
 lib.dw_variant_lnt.restype = C.c_int
 lib.dw_variant_lnt.argtypes = lib.dw_variant_ln3.argtypes
-for (N, H, Cc) in [(16, 160, 96), (16, 80, 192), (16, 40, 384), (16, 20, 768), (32, 160, 96), (32, 80, 192)]:
+for (N, H, Cc) in [(16, 160, 96), (16, 80, 192), (16, 40, 384), (16, 20, 768), (32, 160, 96), (32, 80, 192), (32, 20, 768), (64, 40, 768)]:
     x = torch.randn(N, H, H, Cc, device="cuda").bfloat16()
     w = (torch.randn(49, Cc, device="cuda") / 7).bfloat16()
     b, lw, lb = torch.randn(Cc, device="cuda") * 0.1, torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda") * 0.1
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ref = None
     for rep in range(2):
-        for v in range(6):
-            if (v in (1, 3) and H % 16) or (v == 5 and H % 8):
+        for v in range(9):
+            if (v in (1, 3, 8) and H % 16) or (v == 5 and H % 8):
                 continue
             y = torch.empty_like(x)
             args = (v, x.data_ptr(), w.data_ptr(), b.data_ptr(), lw.data_ptr(), lb.data_ptr(), 1e-6, y.data_ptr(), N, H, H, Cc, s)

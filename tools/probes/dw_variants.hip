@@ -88,6 +88,10 @@ static int ln_tiles(int id, const void* x, const void* w, const float* bias, con
     LNT(3, 4, 16, 4, true)
     LNT(4, 4, 8, 4, false)
     LNT(5, 4, 8, 4, true)
+    // one wave per SIMD (up to 512 registers: no spills in the six-chunk kernel)
+    case 6: return launch_dw<bf16_t, 7, true, 4, 8, MAXCH, 4, 0, false, 1>(x, w, bias, lnw, lnb, eps, nullptr, nullptr, 0, y, nullptr, nullptr, N, H, W, C, s);
+    case 7: return launch_dw<bf16_t, 7, true, 4, 16, MAXCH, 8, 0, false, 1>(x, w, bias, lnw, lnb, eps, nullptr, nullptr, 0, y, nullptr, nullptr, N, H, W, C, s);
+    case 8: return launch_dw<bf16_t, 7, true, 4, 16, MAXCH, 8, 0, true, 1>(x, w, bias, lnw, lnb, eps, nullptr, nullptr, 0, y, nullptr, nullptr, N, H, W, C, s);
   }
 #undef LNT
   return -100;
@@ -99,6 +103,6 @@ extern "C" int dw_variant_lnt(int id, const void* x, const void* w, const float*
   if (nch == 1) return ln_tiles<1>(id, x, w, bias, lnw, lnb, eps, y, N, H, W, C, s);
   if (nch == 2) return ln_tiles<2>(id, x, w, bias, lnw, lnb, eps, y, N, H, W, C, s);
   if (nch == 3) return ln_tiles<3>(id, x, w, bias, lnw, lnb, eps, y, N, H, W, C, s);
-  if (nch == 6 && id >= 4) return ln_tiles<6>(id, x, w, bias, lnw, lnb, eps, y, N, H, W, C, s);
+  if (nch == 6 && id >= 4 && id != 7 && id != 8) return ln_tiles<6>(id, x, w, bias, lnw, lnb, eps, y, N, H, W, C, s);
   return -100;
 }
