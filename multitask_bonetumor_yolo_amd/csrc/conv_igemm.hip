@@ -149,9 +149,10 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
         a->W % 16 == 0 && a->out_mode == MTBT_OUT_NHWC && a->C % (128 / es) == 0 && a->K > 32 &&
         (long)a->H * a->W * a->x_pixel_stride * es < 0x7fff0000L && (long)128 * 9 * a->C * es < 0x7fff0000L) {
       int tc = (a->K >= 96 && !(pol & 32)) ? 128 : 64;
-      // row-reuse variant (conv3x3_rr_kernel): the default for 64-channel tiles (head convs, 6 % faster there; policy bit 4
-      // turns that off), everywhere with policy bit 3 / hint bit 25
-      if ((pol & 8) || ((a->tile_hint >> 25) & 1) || (tc == 64 && !(pol & 16))) tc |= 0x1000;
+      // row-reuse variant (conv3x3_rr_kernel): the default (round 1: only for 64-channel tiles; after the epilogue split it is also
+      // 9 % faster on the 128-channel C2f convs and 3 % on Proto -- MTBT_CONV_POLICY A/B, 7.20 -> 7.15 ms per step); policy bit 4
+      // selects the first formulation, hint bit 25 / policy bit 3 force this one
+      if ((pol & 8) || ((a->tile_hint >> 25) & 1) || !(pol & 16)) tc |= 0x1000;
       const long rows = (long)a->N * (a->H >> 4) * (a->W >> 4) * ((tc & 0x1000) ? 2 : 4);   // partial rows per 16x16 tile: see conv3x3_direct.inc
       if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; return MTBT_OK; }
       if (want_cs && a->colsum_ws_bytes < rows * p.cs_pitch * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;

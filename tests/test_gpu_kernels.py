@@ -95,6 +95,18 @@ def test_conv_igemm(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    (2, 32, 48, 128, 256, 3, 1, 1, 1, True, 0),      # two channel tiles, residual, 2 images
+    (1, 16, 32, 64, 64, 3, 1, 1, 2, False, 0),       # TC = 64, single channel chunk
+    (1, 48, 16, 192, 96, 3, 1, 1, 1, False, 0),      # K = 96 (ragged channel tile), 3 chunks
+])
+def test_conv3x3_direct_first_formulation(dtype, cfg, monkeypatch):
+    """The row-reuse kernel is the default direct 3x3 kernel; policy bit 4 selects the first formulation (conv3x3_direct_kernel): same shapes."""
+    monkeypatch.setenv("MTBT_CONV_POLICY", str(7 | 16))
+    test_conv_igemm(dtype, cfg)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_channel_slices_and_f32_out(dtype):
     """Concat-free C2f addressing: read a channel slice, write a channel slice of a wider buffer; fp32 output."""
     g = torch.Generator().manual_seed(3)
