@@ -10,7 +10,8 @@
 //       two 16-byte (f32) coalesced stores.
 // The caller guarantees the main loop is over (barrier) before the slabs are written.
 // (Measured alternative: 8-byte stores straight from the accumulators, no LDS pass -- 3.5 % SLOWER over the network's
-// convs, although the same idea wins in mlp_fused.hip where the slab form needed four passes of 12-piece rows.)
+// convs in round 1 and again 1.3 % slower per step in round 2 after the epilogue split, although the same idea wins in
+// mlp_fused.hip where the slab form needed four passes of 12-piece rows.)
 #pragma once
 #include "common.h"
 #include "conv_params.h"
