@@ -273,7 +273,7 @@ class Plan:
         dependencies become event record / wait pairs."""
         import os
         n_lanes = self.lanes()
-        wide_s = float(os.environ.get("MTBT_LANE_WIDE_US", "60")) * 1e-6
+        wide_s = float(os.environ.get("MTBT_LANE_WIDE_US", "600")) * 1e-6   # (round 2: 60 -> 600 us after the kernels got faster: only Proto-class launches stay serialized; 7.13 -> 7.03 ms)
         c = self.__dict__.get("_sched")
         if c is not None and c.n_launches == len(self.launches) and c.n_lanes == n_lanes and c.wide_s == wide_s:
             return c
