@@ -292,7 +292,10 @@ class Plan:
             # waited on the first (a fork/join nested below a non-origin stream) segfaults hipStreamEndCapture on ROCm 7.2
             # (tools/capture_topo.py).  So a launch may sit on lane 0, or on the one side lane its dependencies live on.
             side = {lane[j] for j in deps[i]} - {0}
-            allowed = range(n_lanes) if not side else ([0] + list(side) if len(side) == 1 else [0])
+            if getattr(self, "lane_any", False):      # never captured into a HIP graph (training plans): any lane may wait on any other
+                allowed = range(n_lanes)
+            else:
+                allowed = range(n_lanes) if not side else ([0] + list(side) if len(side) == 1 else [0])
             best = min(allowed, key=lambda k: (max(ready, free[k]), k))
             if crit >= 0 and lane[crit] in allowed and free[lane[crit]] <= max(ready, free[best]) + 1e-9:
                 best = lane[crit]

@@ -87,6 +87,7 @@ class TPlan(Plan):
     def __init__(self, device, ws: WsPool):
         super().__init__(device)
         self.wsp = ws
+        self.lane_any = os.environ.get("MTBT_TRAIN_LANE_ANY", "1") != "0"   # eager execution only: no capture-topology restriction on cross-lane waits
         self.cur_ws: Optional[torch.Tensor] = None
         self._late: List[torch.Tensor] = []
         self.pool.reuse = False
