@@ -449,7 +449,8 @@ int pick_split(int K, int C, int taps, long P) {
   const long tiles = (long)((K + TK - 1) / TK) * ((C + TCH - 1) / TCH) * taps;
   auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
 #ifndef MTBT_WGRAD_TARGET
-#define MTBT_WGRAD_TARGET 1024   // workgroups aimed at (batch-32 shapes, tools/wgrad_ab.py: 1536 -> 1024 is 12 % less time: fewer fp32 partial copies of dW)
+#define MTBT_WGRAD_TARGET 512    // workgroups aimed at (batch-32 shapes, tools/wgrad_ab.py: 1536 -> 1024 was 12 % less time: fewer fp32 partial copies of dW; 512 once the
+                                  // weight gradients run BESIDE other launches on the plan's lanes: -0.6 % per step, 256 the same)
 #endif
   long ns = cdiv(MTBT_WGRAD_TARGET, tiles);
   ns = ns < cdiv(P, 24 * TPX) ? ns : cdiv(P, 24 * TPX);
