@@ -38,6 +38,7 @@ SHAPES = {
 
 def bench(shape, hint, dtype=torch.bfloat16, iters=20):
     N, H, W, C, K, k, act, use_res = shape
+    N = int(os.environ.get("MTBT_TUNE_BATCH", N))      # (the training step runs the same layers at batch 32)
     p = Plan(DEV)
     x = Act.of(torch.randn(N, H, W, C, device=DEV).to(dtype))
     w = (torch.randn(K, k * k * C, device=DEV) / (k * k * C) ** 0.5).to(dtype)
