@@ -35,6 +35,12 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
   else if (K > 32) tc = 64;
   else tc = 32;
   const long ct = (K + tc - 1) / tc;
+  if (taps == 1 && (pol & 1) && !no96 && K % 96 == 0 && tc == 128 && ((M + 127) / 128) * (K / 96) >= 3000) {
+    // large 1x1 GEMMs whose width is a multiple of both: 96-channel tiles (batch-32 sweep, profiles/r02_j_conv_tune_1x1_batch32.txt: fc1 of
+    // stages 0-2 3-9 % ahead of 128x128; level at batch 16)
+    *TC = 96; *TP = 128; *narrow = (C * es <= 1536) ? 1 : 0;
+    return;
+  }
   if (taps == 1 && (pol & 1)) {
     // round-2 sweep (profiles/r02_f_conv_tune_1x1.txt, after the epilogue was split by activation): 128x128 tiles once the grid holds >= 4 of
     // them per CU (fc1 of every stage, the C2f 1x1s at P3: 6-18 % faster than 128x64), 128x64 below that; 64-byte K-steps for short rows
