@@ -325,11 +325,12 @@ class _Lowering:
 
     @staticmethod
     def fused_dims():
-        """ConvNeXt widths whose MLP runs as ONE launch (mlp_fused.hip).  d = 384 is built and tested too (MTBT_FUSED_DIMS="96:192:384") but
-        measured equal to the two GEMMs inside the step (7.62 vs 7.61 ms, profiles/r02_notes.md): at one wave per SIMD its GELU and
-        fragment reads are no longer covered by a partner wave."""
+        """ConvNeXt widths whose MLP runs as ONE launch (mlp_fused.hip): stages 0-2.  d = 384 measures EQUAL to its two GEMMs inside the step
+        (7.062 vs 7.064 ms at batch 16 x 640^2, 92.0 vs 91.9 ms at batch 64 x 1280^2 fp16: at one wave per SIMD its GELU and fragment reads
+        are not covered by a partner wave) and is on because the 4d-wide hidden tensor (79 MB per block at batch 16) then never reaches
+        HBM; d = 768 is not built (one weight stage is 98 KiB of LDS).  MTBT_FUSED_DIMS="96:192" restores the two-GEMM form (A/B)."""
         env = os.environ.get("MTBT_FUSED_DIMS")
-        return tuple(int(v) for v in env.replace(":", ",").split(",")) if env else (96, 192)
+        return tuple(int(v) for v in env.replace(":", ",").split(",")) if env else (96, 192, 384)
 
     def subbatch(self, stage: int, a: Act) -> int:
         """Images per depth-first pass of a ConvNeXt stage.  Measured (bench.py --ab MTBT_SUBBATCH=...): keeping the 4d-wide
