@@ -144,8 +144,11 @@ constexpr int NMS_BINS = 4096;      // score histogram (aliases the kept-box cac
 constexpr int NMS_TARGET = 1024;    // preselect at least this many candidates ...
 constexpr int NMS_SEL_MAX = 4096;   // ... and sort everything at once when the top bins hold more than this
 
-// monotone non-decreasing in the score (any float): a candidate in a lower bin has a strictly smaller score
-__device__ __forceinline__ int nms_bin(float v) { return (int)fminf(fmaxf(v * (float)NMS_BINS, 0.f), (float)(NMS_BINS - 1)); }
+// monotone non-decreasing in the score (any float; lo / scale = the candidates' own score range, so that scores crowded into a narrow
+// band -- random-initialised heads: everything near 0.5 -- still spread over the bins): a candidate in a lower bin has a strictly smaller score
+__device__ __forceinline__ int nms_bin(float v, float lo, float scale) {
+  return (int)fminf(fmaxf((v - lo) * scale, 0.f), (float)(NMS_BINS - 1));
+}
 
 __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ score,
                                                      const int* __restrict__ label, int A, float conf_th, float iou_th,
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ b
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int wave_tot[NMS_NW];
   __shared__ int s_cnt, s_bin, s_sel, s_redo, s_nkept;
+  __shared__ unsigned s_lo, s_hi;        // orderable(min / max candidate score)
   __shared__ unsigned long long part_supp[NMS_NW * 64], part_dead[NMS_NW];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* wsi = ws + (long)n * ws_per_image;
@@ -171,17 +175,29 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ b
 
   // ---- 1. compaction (ascending anchor order) + score histogram ----
   for (int i = tid; i < NMS_BINS; i += NMS_NT) hist[i] = 0;
+  if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0u; }
+  __syncthreads();
   const int per_wave = ((A + NMS_NW - 1) / NMS_NW + 63) / 64 * 64;
   const int a_lo = wave * per_wave, a_hi = min(A, a_lo + per_wave);
   int mine = 0;
+  unsigned lo_u = 0xffffffffu, hi_u = 0u;
   for (int a0 = a_lo; a0 < a_hi; a0 += 64) {
     const int a = a0 + lane;
-    mine += __popcll(__ballot(a < a_hi && sc[a] > conf_th));
+    const float v = a < a_hi ? sc[a] : 0.f;
+    const bool f = a < a_hi && v > conf_th;
+    mine += __popcll(__ballot(f));
+    if (f) { const unsigned u = orderable(v); lo_u = min(lo_u, u); hi_u = max(hi_u, u); }
   }
-  if (lane == 0) wave_tot[wave] = mine;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo_u = min(lo_u, (unsigned)__shfl_xor((int)lo_u, o, 64)); hi_u = max(hi_u, (unsigned)__shfl_xor((int)hi_u, o, 64)); }
+  if (lane == 0) { wave_tot[wave] = mine; atomicMin(&s_lo, lo_u); atomicMax(&s_hi, hi_u); }
   __syncthreads();
   int off = 0, M = 0;
   for (int k = 0; k < NMS_NW; ++k) { if (k < wave) off += wave_tot[k]; M += wave_tot[k]; }
+  // the candidates' score range -> histogram bins (orderable() is its own inverse up to the sign handling below)
+  auto unorder = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
+  const float b_lo = M > 0 ? unorder(s_lo) : 0.f, b_hi = M > 0 ? unorder(s_hi) : 1.f;
+  const float b_scale = b_hi > b_lo ? (float)NMS_BINS / (b_hi - b_lo) : 0.f;      // (all equal: one bin, the full sort below)
   for (int a0 = a_lo; a0 < a_hi; a0 += 64) {
     const int a = a0 + lane;
     const float v = a < a_hi ? sc[a] : 0.f;
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ b
     const unsigned long long bal = __ballot(f);
     if (f) {
       cand_anchor[off + __popcll(bal & below)] = a;
-      atomicAdd(&hist[nms_bin(v)], 1);
+      atomicAdd(&hist[nms_bin(v, b_lo, b_scale)], 1);
     }
     off += __popcll(bal);
   }
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const float* __restrict__ b
       if (attempt == 1) {
         if (pos < M) keys[pos] = ((unsigned long long)(~orderable(v)) << 32) | (unsigned)pos;
       } else {
-        const bool f = pos < M && nms_bin(v) >= sel_bin;
+        const bool f = pos < M && nms_bin(v, b_lo, b_scale) >= sel_bin;
         const unsigned long long bal = __ballot(f);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&s_cnt, __popcll(bal));
