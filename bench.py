@@ -68,6 +68,12 @@ def cpu_baseline(seconds_budget=14.0):
             "sample": f"oracle fp32 forward + decode/NMS/masks at {IMG}x{IMG}: batch 1, 3 warm-ups + {n1} iterations; batch 16, 1 warm-up + {n16} iterations"}
 
 
+def kept_score_range(res):
+    valid = torch.arange(res["scores"].shape[1], device=res["scores"].device)[None, :] < res["counts"][:, None]
+    sc = res["scores"][valid]
+    return [round(float(sc.min().item()), 4), round(float(sc.max().item()), 4)] if sc.numel() else None
+
+
 def synthetic_targets(B, S, seed, dev):
     """per image 1-3 GT boxes (cx, cy ~ U(.2,.8), w, h ~ U(.05,.4)), masks = the filled box rectangles, image class ~ {0,1}."""
     g = torch.Generator().manual_seed(1000 + seed)
@@ -142,6 +148,7 @@ def main():
     ap.add_argument("--img", type=int, default=IMG, help="image side (default 640 = the benchmark configuration; 1280 = BASELINE configs[4]'s shape)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="f16 = BASELINE configs[4]'s arithmetic (inference only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--raw-heads", action="store_true", help="dev: skip the synthetic-head calibration (every anchor scores ~0.5: round 1-2's degenerate post-process load)")
     ap.add_argument("--no-graph", action="store_true", help="issue the ~220 launches of a step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
     ap.add_argument("--ab-graph", default="", help="dev: comma list of VAR=val; each is re-lowered, re-captured and its graph replay timed")
@@ -171,7 +178,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, GraphedInference, init_synthetic_, postprocess as pp
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, GraphedInference, calibrate_synthetic_heads_, init_synthetic_, postprocess as pp
 
     torch.manual_seed(0)
     model = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
@@ -179,6 +186,10 @@ def main():
     B = args.batch
     globals()["IMG"] = args.img
     x = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(rank)).to(dev)  # resident in HBM
+    if not args.raw_heads:
+        # ~10^3 of the 8400 anchors per image pass conf 0.05, scores spread over (0.01, 0.99) -- a random-initialised class
+        # branch scores every anchor ~0.5 (8400 candidates, a saturated top-100 decided below bf16's resolution: round 2's VERDICT)
+        calibrate_synthetic_heads_(model, x[: min(B, 4)].contiguous())
 
     def eager_step():
         # drop-in forward(x, "infer") + decode / NMS / masks as one scheduled step (NMS forks under the Segment launches)
@@ -324,7 +335,10 @@ def main():
             "config": {"workload": f"{'configs[1]' if (B, IMG, args.dtype) == (BATCH_PER_GPU, 640, 'bf16') else ('configs[4]' if (B, IMG, args.dtype) == (64, 1280, 'f16') else 'side measurement')}: batch-{B}/GPU {IMG}x{IMG} multitask inference (ConvNeXt-T + C2f-BiFPN + Detect/Segment/cls) "
                                    f"+ decode + per-image NMS(top-100) + mask assembly; random-init weights",
                        "batch_per_gpu": B, "img": IMG, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
-                       "kept_boxes_per_image": float(res["counts"].float().mean().item())},
+                       "heads": "raw random init" if args.raw_heads else "calibrated (SURVEY 8d): class logits std 2, 2 % / 30 % / 90 % of the P3 / P4 / P5 anchors above conf 0.05",
+                       "n_cand_per_image": float(res["n_cand"].float().mean().item()),
+                       "kept_boxes_per_image": float(res["counts"].float().mean().item()),
+                       "kept_score_range": kept_score_range(res)},
             "roofline": roofline, "roofline_3x3": roofline_3x3, "roofline_hbm": roofline_hbm,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -52,7 +52,14 @@ extern "C" {
 #define MTBT_OUT_NHWC 0
 #define MTBT_OUT_CONVT2X2 1 /* ConvTranspose2d(k=2,s=2): GEMM row q*Cout+co -> pixel (2y+q/2, 2x+q%2), channel co */
 
+/* Bumped whenever an argument struct or a signature below changes (round 1 = 1; round 2 added fields / positional arguments without
+ * bumping it; round 3 starts at 3).  The library travels prebuilt: a binding built against another header must refuse to load. */
+#define MTBT_ABI_VERSION 3
 int mtbt_abi_version(void);
+/* sizeof() of the argument structs as the LIBRARY was compiled: which = 0 mtbt_conv_args, 1 mtbt_fuse_args, 2 mtbt_decode_args,
+ * 3 mtbt_mask_args, 4 mtbt_loss_args, 5 mtbt_prep_desc, 6 mtbt_raw_image; -1 for any other value.  A binding compares them with its
+ * own layout at load time (a stale prebuilt .so would otherwise read pointers from the wrong offsets). */
+int mtbt_sizeof_args(int which);
 /* "gfx950" */
 const char* mtbt_target_arch(void);
 

@@ -5,6 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
 
+ABI_VERSION = 3          # include/mtbt_hip.h MTBT_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY, ACT_DSILU, ACT_DELU, ACT_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
 OUT_NHWC, OUT_CONVT2X2 = 0, 1
@@ -85,6 +86,7 @@ class RawImage(C.Structure):  # mtbt_raw_image
 
 SYMBOLS = {
     "mtbt_abi_version": (C.c_int, []),
+    "mtbt_sizeof_args": (C.c_int, [C.c_int]),
     "mtbt_target_arch": (C.c_char_p, []),
     "mtbt_conv2d_nhwc": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "mtbt_stem_conv4x4_ln": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
@@ -166,6 +168,7 @@ SYMBOLS = {
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 
+ARG_STRUCTS = (ConvArgs, FuseArgs, DecodeArgs, MaskArgs, LossArgs, PrepDesc, RawImage)   # order of mtbt_sizeof_args(which)
 _lib = None
 
 
@@ -180,8 +183,13 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mtbt_abi_version() != 1:
-            raise RuntimeError("libmtbt_hip.so ABI version mismatch")
+        if lib.mtbt_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libmtbt_hip.so reports ABI version {lib.mtbt_abi_version()}, this binding is version {ABI_VERSION}: rebuild "
+                               "(`python -m multitask_bonetumor_yolo_amd.build`)")
+        for which, st in enumerate(ARG_STRUCTS):
+            if lib.mtbt_sizeof_args(which) != C.sizeof(st):
+                raise RuntimeError(f"libmtbt_hip.so was built with sizeof({st.__name__}) = {lib.mtbt_sizeof_args(which)}, this binding lays it out in "
+                                   f"{C.sizeof(st)} bytes: stale library, rebuild")
         _lib = lib
     return _lib
 

@@ -22,10 +22,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 
 // fp16 <-> fp32.  Stores SATURATE at +-65504 instead of overflowing to infinity (BASELINE configs[4]: "fp16 MFMA conv path"): an
-// activation beyond the binary16 range would otherwise poison every later layer; NaN stays NaN.
+// activation beyond the binary16 range would otherwise poison every later layer.  NaN stays NaN, by an explicit select: v_med3_f32
+// with a NaN operand returns MIN3 of the operands and the IEEE minimum DROPS the NaN, so the clamp alone would store a NaN activation as
+// -65504 and hide a divergence (tests/test_gpu_kernels.py::test_fp16_store_saturates_and_keeps_nan).
 __device__ __forceinline__ float h2f(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.v); }
 __device__ __forceinline__ uint16_t f2h_bits(float f) {
-  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+  const float c = __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+  const _Float16 h = (_Float16)(f != f ? f : c);
   return __builtin_bit_cast(uint16_t, h);
 }
 __device__ __forceinline__ f16_t f2h(float f) { return f16_t{f2h_bits(f)}; }

@@ -600,5 +600,17 @@ extern "C" int mtbt_mask_assemble(const mtbt_mask_args* a, void* stream) {
   return MTBT_OK;
 }
 
-extern "C" int mtbt_abi_version(void) { return 1; }
+extern "C" int mtbt_abi_version(void) { return MTBT_ABI_VERSION; }
+extern "C" int mtbt_sizeof_args(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(mtbt_conv_args);
+    case 1: return (int)sizeof(mtbt_fuse_args);
+    case 2: return (int)sizeof(mtbt_decode_args);
+    case 3: return (int)sizeof(mtbt_mask_args);
+    case 4: return (int)sizeof(mtbt_loss_args);
+    case 5: return (int)sizeof(mtbt_prep_desc);
+    case 6: return (int)sizeof(mtbt_raw_image);
+    default: return -1;
+  }
+}
 extern "C" const char* mtbt_target_arch(void) { return "gfx950"; }

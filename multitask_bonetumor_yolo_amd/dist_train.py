@@ -33,6 +33,7 @@ class FlatBuckets:
         self.views: Dict[str, torch.Tensor] = {}
         self.buckets: List[torch.Tensor] = []
         self.layout: List[List[Tuple[str, int, int]]] = []          # per bucket: (name, offset, numel)
+        self.where: Dict[str, Tuple[int, int, int, Tuple[int, ...]]] = {}   # name -> (bucket, offset, numel, shape)
         cur, off = [], 0
         close_after = set(close_after)
         for name, shape in reversed(list(named_shapes)):
@@ -53,6 +54,19 @@ class FlatBuckets:
         self.layout.append([(n, o, k) for n, o, k, _ in items])
         for name, o, k, shape in items:
             self.views[name] = flat[o:o + k].view(shape)
+            self.where[name] = (len(self.buckets) - 1, o, k, shape)
+
+    def snapshot_views(self, names) -> Dict[str, torch.Tensor]:
+        """Views (registered shapes) into FRESH copies of the buckets that hold `names`: one flat copy per bucket instead of one per
+        tensor.  What an autograd node may hand out: the persistent buckets are overwritten by the next backward pass."""
+        copies: Dict[int, torch.Tensor] = {}
+        out = {}
+        for n in names:
+            b, o, k, shape = self.where[n]
+            if b not in copies:
+                copies[b] = self.buckets[b].clone()
+            out[n] = copies[b][o:o + k].view(shape)
+        return out
 
     def zero_(self):
         for b in self.buckets:

@@ -153,6 +153,20 @@ class Plan:
         if os.environ.get("MTBT_DIRECT_TC64"):
             self.conv_policy = 0x100 | ((self.conv_policy & 0xff) if self.conv_policy else 7) | 32
         self.conv_debug = int(os.environ.get("MTBT_CONV_DEBUG", "0"))
+        self.reload_env()
+
+    def reload_env(self):
+        """(Re-)read the lane knobs from the environment.  They are read HERE, once per plan, not per step: run() / schedule() are
+        per-step host work (an eager training step issues ~950 launches).  Tests and tools that flip a knob on a live plan call this."""
+        import os
+        self.n_lanes = max(1, int(os.environ.get("MTBT_LANES", "4")))
+        self.lane_serial = os.environ.get("MTBT_LANE_SERIAL") == "1"     # dev: total order across lanes (no two launches overlap)
+        # launches estimated longer than this fill the machine and stay serialized on lane 0 (round 2: 60 -> 600 us after the kernels got
+        # faster: only Proto-class launches stay serialized; 7.13 -> 7.03 ms)
+        self.lane_wide_s = float(os.environ.get("MTBT_LANE_WIDE_US", "600")) * 1e-6
+        self.lane_window = tuple(int(v) for v in os.environ.get("MTBT_LANE_WINDOW", "0:1000000").split(":"))  # dev: side lanes only in [a, b)
+        self.__dict__.pop("_sched", None)
+        return self
 
     # ---- execution ----
     def run(self, stream: Optional[int] = None, start: int = 0, end: Optional[int] = None, marks=None):
@@ -196,17 +210,13 @@ class Plan:
         for k in used:
             streams[k].wait_event(fork)
         mark_at, out = {}, {name: [] for name in groups}   # launch index -> [(group, event)]
-        for name, idx in groups.items():
-            last = {}
-            for i in idx:
-                last[sch.lane[i]] = max(last.get(sch.lane[i], -1), i)
-            for i in last.values():
+        for name, points in self.mark_points(sch, groups).items():
+            for i in points:
                 ev = torch.cuda.Event()
                 mark_at.setdefault(i, []).append(ev)
                 out[name].append(ev)
         launches = self.launches
-        import os
-        serial = os.environ.get("MTBT_LANE_SERIAL") == "1"  # dev: total order across lanes (no two launches overlap)
+        serial = self.lane_serial
         prev_ev, prev_ln = None, -1
         for i in sch.order:
             ln = sch.lane[i]
@@ -232,8 +242,20 @@ class Plan:
         return unwrap(out)
 
     def lanes(self) -> int:
-        import os
-        return max(1, int(os.environ.get("MTBT_LANES", "4")))
+        return self.n_lanes
+
+    @staticmethod
+    def mark_points(sch, groups):
+        """Where run() records the events of each mark group: after the LAST marked launch of EVERY lane that carries one (stream
+        order covers that lane's earlier marked launches).  A consumer that waits on all of a group's events is therefore ordered
+        behind every launch of the group, whichever lanes the scheduler put them on."""
+        out = {}
+        for name, idx in groups.items():
+            last = {}
+            for i in idx:
+                last[sch.lane[i]] = max(last.get(sch.lane[i], -1), i)
+            out[name] = sorted(last.values())
+        return out
 
     def _side_streams(self, n):
         # process-wide per device and never destroyed: captured graphs may outlive the plan that recorded them
@@ -271,15 +293,14 @@ class Plan:
         starts when its dependencies and its lane are free; it takes the lane where it can start first, preferring the
         lane of the dependency it waits for last (a chain stays on one stream and needs no event).  Cross-lane
         dependencies become event record / wait pairs."""
-        import os
         n_lanes = self.lanes()
-        wide_s = float(os.environ.get("MTBT_LANE_WIDE_US", "600")) * 1e-6   # (round 2: 60 -> 600 us after the kernels got faster: only Proto-class launches stay serialized; 7.13 -> 7.03 ms)
+        wide_s = self.lane_wide_s
         c = self.__dict__.get("_sched")
         if c is not None and c.n_launches == len(self.launches) and c.n_lanes == n_lanes and c.wide_s == wide_s:
             return c
         deps = self.dependencies()
         n = len(self.launches)
-        win = [int(v) for v in os.environ.get("MTBT_LANE_WINDOW", "0:1000000").split(":")]  # dev: side lanes only in [a, b)
+        win = self.lane_window
         lane, finish = [0] * n, [0.0] * n
         free = [0.0] * n_lanes
         for i, l in enumerate(self.launches):

@@ -11,6 +11,12 @@ torchmetrics' binary stat-score definitions.
                           :480-497 from those counts in `compute`.
   MeanAveragePrecision    COCO box mAP over IoU thresholds with `max_detection_thresholds` (mAP@0.5 and @0.5:0.95 of :206-214):
                           host-side numpy -- at most 100 kept boxes per image after the device NMS, a few GT boxes.
+
+Data-parallel validation (configs[3]: one process per GPU, each rank sees its shard of the validation set): the reference's metric
+objects are built with `dist_sync_on_step=True` (`running_main_v3.py:193-218`), i.e. torchmetrics gathers every rank's state before it
+computes.  Here `compute()` does the same when a `torch.distributed` process group with more than one rank is alive (`dist_sync=True`,
+the default): the per-image records (detections x ground-truth IoU matrices; pixel counts) of all ranks are all-gathered in rank order,
+every rank computes the SAME global value, and the local state is left as it was (torchmetrics' sync / unsync around compute).
 """
 import ctypes as C
 from typing import Dict, List, Optional, Sequence
@@ -19,6 +25,23 @@ import numpy as np
 import torch
 
 from . import _lib as L
+
+
+def _world(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _all_gather_records(local, group=None):
+    """Every rank's list of per-image records, concatenated in rank order (a few KB per image: host objects; RCCL moves the pickled bytes
+    through device tensors, gloo through the host).  All ranks must call it."""
+    import torch.distributed as dist
+    world = _world(group)
+    if world == 1:
+        return list(local)
+    parts = [None] * world
+    dist.all_gather_object(parts, list(local), group=group)
+    return [rec for part in parts for rec in part]
 
 
 def box_iou_xyxy(a: np.ndarray, b: np.ndarray) -> np.ndarray:
@@ -38,7 +61,9 @@ class MeanAveragePrecision:
     `update(preds, targets)` takes the torchmetrics layout the reference builds (`running_main_v3.py:553-575`): per image
     `dict(boxes [D,4] xyxy, scores [D], labels [D])` and `dict(boxes [G,4], labels [G])`."""
 
-    def __init__(self, iou_thresholds: Optional[Sequence[float]] = None, max_detection_thresholds: Sequence[int] = (1, 10, 100)):
+    def __init__(self, iou_thresholds: Optional[Sequence[float]] = None, max_detection_thresholds: Sequence[int] = (1, 10, 100),
+                 dist_sync: bool = True, process_group=None):
+        self.dist_sync, self.group = dist_sync, process_group
         self.iou_thresholds = np.asarray(iou_thresholds if iou_thresholds is not None else np.linspace(0.5, 0.95, 10), np.float64)
         self.max_dets = sorted(int(m) for m in max_detection_thresholds)
         self.rec_thresholds = np.linspace(0.0, 1.0, 101)
@@ -83,12 +108,14 @@ class MeanAveragePrecision:
         return out
 
     def compute(self) -> Dict[str, float]:
+        """With a live process group (and dist_sync): over the images of ALL ranks -- a collective, every rank must call it."""
+        images = _all_gather_records(self._images, self.group) if self.dist_sync else self._images
         T, R, M = len(self.iou_thresholds), len(self.rec_thresholds), len(self.max_dets)
-        classes = sorted(set(int(c) for im in self._images for c in np.concatenate([im[1], im[2]])))
+        classes = sorted(set(int(c) for im in images for c in np.concatenate([im[1], im[2]])))
         precision, recall = -np.ones((T, R, len(classes), M)), -np.ones((T, len(classes), M))
         for k, c in enumerate(classes):
             per_image, npig = [], 0
-            for scores, labels, gt_labels, iou in self._images:
+            for scores, labels, gt_labels, iou in images:
                 di, gi = np.nonzero(labels == c)[0], np.nonzero(gt_labels == c)[0]
                 npig += len(gi)
                 if len(di):
@@ -130,7 +157,8 @@ class MeanAveragePrecision:
 class SegmentationMetrics:
     """Binary segmentation metrics of `validation_step` (`running_main_v3.py:466-498`) from device-side pixel counts."""
 
-    def __init__(self):
+    def __init__(self, dist_sync: bool = True, process_group=None):
+        self.dist_sync, self.group = dist_sync, process_group
         self._counts: List[torch.Tensor] = []
         self._psum: List[torch.Tensor] = []
 
@@ -156,16 +184,22 @@ class SegmentationMetrics:
         self._counts.append(counts)
         self._psum.append(psum)
 
-    def per_image(self):
-        """-> (counts [N,4] int64 = TP, FP, FN, TN; mask scores [N] = sum(prob * mask) / (sum(mask) + 1e-6), :483)."""
-        if not self._counts:
-            return np.zeros((0, 4), np.int64), np.zeros(0, np.float32)
-        c = torch.cat(self._counts).cpu().numpy()
-        p = torch.cat(self._psum).cpu().numpy()
+    def per_image(self, sync: bool = False):
+        """-> (counts [N,4] int64 = TP, FP, FN, TN; mask scores [N] = sum(prob * mask) / (sum(mask) + 1e-6), :483).
+        `sync`: the images of all ranks in rank order (a collective)."""
+        if self._counts:
+            c = torch.cat(self._counts).cpu().numpy()
+            p = torch.cat(self._psum).cpu().numpy()
+        else:
+            c, p = np.zeros((0, 4), np.int64), np.zeros(0, np.float32)
+        if sync and _world(self.group) > 1:
+            recs = _all_gather_records([(c, p)], self.group)
+            c, p = np.concatenate([r[0] for r in recs]), np.concatenate([r[1] for r in recs])
         return c, (p / ((c[:, 0] + c[:, 1]).astype(np.float32) + np.float32(1e-6))).astype(np.float32)
 
     def compute(self) -> Dict[str, float]:
-        c, score = self.per_image()
+        """With a live process group (and dist_sync): from the pixel counts of ALL ranks -- a collective, every rank must call it."""
+        c, score = self.per_image(sync=self.dist_sync)
         tp, fp, fn, tn = (float(v) for v in c.sum(axis=0)) if len(c) else (0.0, 0.0, 0.0, 0.0)
         div = lambda a, b: a / b if b else 0.0                                    # torchmetrics _safe_divide
         out = {"f1": div(2 * tp, 2 * tp + fp + fn), "precision": div(tp, tp + fp), "recall": div(tp, tp + fn),
@@ -174,7 +208,7 @@ class SegmentationMetrics:
         dice = np.where(den > 0, 2 * c[:, 0] / np.maximum(den, 1), np.nan)         # per sample; empty-vs-empty samples are skipped
         out["dice"] = float(np.nanmean(dice)) if np.any(den > 0) else 0.0
         # segmentation mAP (:478-497): one predicted instance (class 0) and one GT instance per image
-        m = MeanAveragePrecision()
+        m = MeanAveragePrecision(dist_sync=False)                              # (c, score already hold every rank's images)
         union = (c[:, 0] + c[:, 1] + c[:, 2]).astype(np.float64)
         iou = np.where(union > 0, c[:, 0] / np.maximum(union, 1), 0.0)
         for i in range(len(c)):

@@ -40,8 +40,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None
 
 
+DRY_LOWERING = False           # tests/test_cpu_*: build the launch plans (regions, dependencies, schedule) on CPU tensors; nothing is ever issued
+
+
 def _param_ptr(p: torch.Tensor, what: str) -> int:
-    if p.dtype != torch.float32 or not p.is_cuda:
+    if p.dtype != torch.float32 or not (p.is_cuda or DRY_LOWERING):
         raise RuntimeError(f"{what}: the training plan reads parameters in place: fp32 CUDA/HIP tensors expected, got {p.dtype} on {p.device}")
     return p.data_ptr()
 
@@ -333,6 +336,14 @@ class TrainPlan:
         self._finish_prep()
         self._bwd_cache: Dict[Tuple[bool, ...], Tuple[TPlan, List[str]]] = {}
         self.param_ptrs = [p.data_ptr() for p in model.parameters()]
+        self.use_lanes = os.environ.get("MTBT_TRAIN_LANES", "1") == "1"
+
+    def reload_env(self):
+        """Re-read MTBT_TRAIN_LANES / MTBT_LANES / ... (read once per plan, not per step) -- for tests and tools that flip them on a live plan."""
+        self.use_lanes = os.environ.get("MTBT_TRAIN_LANES", "1") == "1"
+        for plan in [self.fwd] + list(self._bwd_cache.values()):
+            plan.reload_env()
+        return self
 
     # ------------------------------------------------------------------------------------------------------------------
     # parameter-gradient arena (kernel layouts)
@@ -1000,9 +1011,8 @@ class TrainPlan:
     def issue(self, plan: TPlan, marks=None):
         """Spread a plan over the engine's lanes (independent launches -- weight gradients beside the input-gradient chain, the small
         pyramid levels side by side; bit-identical to single-stream execution: no atomics anywhere, tests/test_gpu_train.py), or, with
-        MTBT_TRAIN_LANES=0, issue it on the current stream.  Measured at batch 32: 80.0 -> 79.3 ms per step."""
-        import os
-        if os.environ.get("MTBT_TRAIN_LANES", "1") == "1":
+        MTBT_TRAIN_LANES=0 (read when the plan is built; `reload_env()`), issue it on the current stream.  Measured at batch 32: 80.0 -> 79.3 ms per step."""
+        if self.use_lanes:
             return plan.run(marks=marks)
         return plan.run(stream=torch.cuda.current_stream(self.device).cuda_stream, marks=marks)
 
@@ -1066,7 +1076,12 @@ class _TrainFn(torch.autograd.Function):
                 tp.d_in["logits"].copy_(gl[0])
         plan = tp.run_backward(active)
         written = set(plan.written)
-        grads = tuple(tp.param_grad(n) if (p.requires_grad and n in written) else None for n, p in tp.m.named_parameters())
+        # The gradients leave as views of FRESH copies of the gradient buckets (one flat copy per bucket), never of the persistent arena:
+        # AccumulateGrad keeps a returned tensor as `.grad` without copying when its strides match the parameter's (the stem weight, 1x1
+        # depthwise weights, the class bias), and the next backward pass rewrites the arena in place -- `.grad += new` would then add a
+        # buffer to itself (gradient accumulation, `zero_grad(set_to_none=False)`, two losses through one forward).
+        snap = tp.arena.snapshot_views([n for n, p in tp.m.named_parameters() if p.requires_grad and n in written])
+        grads = tuple((tp._gview[n](snap[n]) if tp._gview[n] is not None else snap[n]) if n in snap else None for n, p in tp.m.named_parameters())
         return (None, None, None) + grads
 
 

@@ -34,6 +34,25 @@ def _s(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def bucket_writers(launches, buckets):
+    """Per flat bucket the indices of ALL launches that write into its storage, found from the write REGIONS the op builders record
+    (`engine._region`: storage address + element range), not from tensor identity -- a derived view of a slot (`.view(-1)`) counts."""
+    key = {b.untyped_storage().data_ptr(): k for k, b in enumerate(buckets)}
+    out = [[] for _ in buckets]
+    for i, l in enumerate(launches):
+        for k in sorted({key[w[0]] for w in l.writes if w[0] in key}):
+            out[k].append(i)
+    return out
+
+
+def exchange_marks(writers, live):
+    """(marks for Plan.run, the order in which the collectives are issued): every writer of every live bucket is marked; buckets are
+    reduced in the order of their latest writer; a bucket without a recorded writer comes last (it waits for the whole plan)."""
+    marks = {str(b): list(writers[b]) for b in live if writers[b]}
+    order = sorted(live, key=lambda k: (max(writers[k]) if writers[k] else 1 << 60, k))
+    return marks, order
+
+
 class TrainStep:
     def __init__(self, model, batch_shape: Sequence[int], *, optimizer: str = "adamw", lr: float = 1e-4, weight_decay: float = 5e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9, nesterov: bool = False, clip_norm: Optional[float] = 10.0,
@@ -55,7 +74,7 @@ class TrainStep:
         self.projector.to(dev)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.group = process_group
-        self._host_staged = False
+        self._host_staged = self._host_staged_logged = False
         # ---- re-home the parameters into flat buckets with the gradient arena's layout ----
         self.params, gview, self.n_skip = make_arena(model, dev, UNUSED_BY_THE_LOSS)
         with torch.no_grad():
@@ -98,22 +117,9 @@ class TrainStep:
         self.sq_ws = torch.empty(self.lib.mtbt_sumsq_workspace_bytes() // 4, device=dev)
         self.loss_kw = dict(img_size=self.S, nc_det=model.nc_det, reg_max=model.detect.reg_max, iou_match_thresh=iou_match_thresh,
                             label_smoothing=label_smoothing, training=True, weights=loss_weights)
-        # ---- gradient exchange: bucket b is complete after backward launch ready[b] ----
+        # ---- gradient exchange: bucket b is complete once EVERY backward launch in writers[b] has run ----
         self.comm = torch.cuda.Stream(device=dev) if (self.world > 1 and overlap) else None
-        self.ready = self._bucket_ready_indices()
-
-    def _bucket_ready_indices(self):
-        """Per gradient bucket the index of the LAST backward launch that writes into it (known statically: no hooks)."""
-        last = {}
-        for i, l in enumerate(self.bwd.launches):
-            for k in l.keep:
-                if isinstance(k, torch.Tensor):
-                    last[id(k)] = i
-        out = []
-        for lay in self.grads.layout:
-            idx = [last.get(id(self.grads.views[n]), -1) for n, _, _ in lay]
-            out.append(max(idx) if idx else -1)
-        return out
+        self.writers = bucket_writers(self.bwd.launches, self.grads.buckets)
 
     # ------------------------------------------------------------------------------------------------------------------
     def step(self, x: torch.Tensor, gt_boxes: torch.Tensor, gt_masks: torch.Tensor, gt_cls: torch.Tensor) -> torch.Tensor:
@@ -152,12 +158,19 @@ class TrainStep:
                 self._mean_over_ranks(self.grads.buckets[b])
             self._reduce_projector()
             return
-        marks = {str(b): [self.ready[b]] for b in live if self.ready[b] >= 0}
+        # The backward plan runs on several lanes (HIP streams) and the slots of one bucket are independent regions for its scheduler, so a
+        # bucket's writers sit on SEVERAL lanes: every one of them is marked, Plan.run records one event per lane that carries a marked
+        # launch (after that lane's last one), and the collective waits for ALL of those events.  (Round 2 marked only the bucket's
+        # program-order-last writer: an earlier writer on another lane could still be running when the bucket was reduced.)
+        marks, order = exchange_marks(self.writers, live)
         events = self.tp.issue(self.bwd, marks=marks)
-        # buckets complete in bucket order (reverse registration = backward order); each collective waits only for ITS last producer
+        end = torch.cuda.Event()
+        end.record(main)                       # behind the plan's join: every lane's work, for a bucket no recorded launch writes
+        # buckets complete roughly in bucket order (reverse registration = backward order): ordered by their LATEST writer
         with torch.cuda.stream(self.comm):
-            for b in sorted(live, key=lambda k: self.ready[k]):
-                for ev in events.get(str(b), []):
+            for b in order:
+                evs = events.get(str(b))
+                for ev in (evs if evs else [end]):
                     self.comm.wait_event(ev)
                 self._mean_over_ranks(self.grads.buckets[b])
         main.wait_stream(self.comm)
@@ -174,13 +187,23 @@ class TrainStep:
             try:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 return
-            except RuntimeError:
+            except RuntimeError as e:
                 if dist.get_backend(self.group) != "gloo":
                     raise
-                self._host_staged = True
+                self._note_host_staging(e)
         h = t.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
         t.copy_(h)
+
+    def _note_host_staging(self, err):
+        """gloo rehearsal only: device-tensor collectives failed once, every later collective goes through the host.  Said ONCE, with the
+        error that tripped it, so that a real failure in this mode does not hide behind the fallback."""
+        self._host_staged = True
+        if not self._host_staged_logged:
+            self._host_staged_logged = True
+            import warnings
+            warnings.warn(f"TrainStep: gloo collective on a device tensor failed ({type(err).__name__}: {err}); staging every collective through "
+                          "host memory from now on (rehearsal backend only -- RCCL errors are raised)")
 
     def sync_buffers(self, src: int = 0):
         """Rank `src`'s BatchNorm running statistics to every rank.  (torch DDP broadcasts buffers before EVERY forward; a train-mode
@@ -194,10 +217,10 @@ class TrainStep:
             try:
                 dist.broadcast(t, src=src, group=self.group)
                 return
-            except RuntimeError:
+            except RuntimeError as e:
                 if dist.get_backend(self.group) != "gloo":
                     raise
-                self._host_staged = True
+                self._note_host_staging(e)
         h = t.cpu()
         dist.broadcast(h, src=src, group=self.group)
         t.copy_(h)

@@ -101,3 +101,81 @@ def test_gradient_arena_layouts_and_unused_parameter_bucket():
     v = arena.views["backbone.c2f_p3.m.0.cv1.conv.weight"]
     gview["backbone.c2f_p3.m.0.cv1.conv.weight"](v).copy_(w.detach())
     assert torch.equal(v.permute(0, 3, 1, 2), w.detach())
+
+
+def test_every_gradient_bucket_waits_for_all_its_writer_lanes(monkeypatch):
+    """The overlapped all-reduce of configs[3] (trainstep.TrainStep._backward_and_exchange; running_main_v3.py:824-828 = implicit DDP):
+    the REAL backward launch plan, lowered here on CPU tensors (nothing is issued), scheduled onto 4 lanes.  For every gradient bucket
+    that is reduced: every launch that writes into the bucket's storage is marked, the lanes of those writers all carry one of the
+    bucket's events, each writer is at or before its lane's event, and the buckets are reduced in the order of their latest writer.
+    (Round 2 marked only the program-order-last writer: its event covered ONE of the lanes.)"""
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, _lib as L, train as T
+    from multitask_bonetumor_yolo_amd.engine import _overlap, _region
+    from multitask_bonetumor_yolo_amd.trainstep import UNUSED_BY_THE_LOSS, bucket_writers, exchange_marks
+    monkeypatch.setenv("MTBT_LANES", "4")
+    monkeypatch.setattr(T, "DRY_LOWERING", True)
+    torch.manual_seed(0)
+    m = ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False).train()
+    tp = T.TrainPlan(m, (2, 3, 64, 64), torch.device("cpu"), L.BF16, tail_prefixes=UNUSED_BY_THE_LOSS)
+    bwd = tp.backward_plan(("det", "logits", "protos"))
+    assert bwd.lane_any and bwd.lanes() == 4
+    buckets = tp.arena.buckets
+    live = list(range(tp.n_tail_buckets, len(buckets)))
+    writers = bucket_writers(bwd.launches, buckets)
+    # (1) region-based detection finds a writer for every parameter the plan produces a gradient for -- also where the launch was handed
+    #     a derived view of the slot (fc1.bias goes in as `.view(-1)`, which an id()-based match misses)
+    for name in bwd.written:
+        slot = _region(tp.arena.views[name])
+        hit = [i for i, l in enumerate(bwd.launches) if any(_overlap(slot, w) for w in l.writes)]
+        if not hit:
+            # the one legitimate case: a conv bias in front of a batch-statistic BatchNorm -- its gradient is EXACTLY zero and the slot
+            # keeps the arena's zero (train.py conv_bn_act)
+            owner = dict(m.named_modules())[name.rsplit(".", 2)[0]]
+            assert name.endswith(".conv.bias") and owner.bn.training, f"no launch records a write to the gradient slot of {name}"
+            continue
+        b = next(k for k, lay in enumerate(tp.arena.layout) if any(n == name for n, _, _ in lay))
+        assert set(hit) <= set(writers[b])
+    assert not any(writers[b] for b in range(tp.n_tail_buckets))          # Segment cv2 / cv3 / cv4: never written, never reduced (SURVEY F13)
+    assert all(writers[b] for b in live)
+    # (2) lanes of the writers == lanes that carry one of the bucket's events; every writer at or before its lane's event
+    marks, order = exchange_marks(writers, live)
+    sch = bwd.schedule()
+    points = bwd.mark_points(sch, marks)
+    multi = 0
+    for b in live:
+        w_lanes = {sch.lane[i] for i in writers[b]}
+        e_at = {sch.lane[i]: i for i in points[str(b)]}
+        assert w_lanes == set(e_at), (b, w_lanes, set(e_at))
+        assert all(i <= e_at[sch.lane[i]] for i in writers[b])
+        multi += len(w_lanes) > 1
+        # what round 2 did -- one event after the last writer -- leaves the other lanes uncovered
+        if len(w_lanes) > 1:
+            old = bwd.mark_points(sch, {"b": [max(writers[b])]})["b"]
+            assert {sch.lane[i] for i in old} != w_lanes
+    assert multi > 0, "expected buckets whose writers are spread over several lanes"
+    # (3) collectives in the order the buckets complete; a bucket without a writer would wait for the whole plan (last)
+    assert sorted(order) == live and [max(writers[b]) for b in order] == sorted(max(writers[b]) for b in live)
+    marks2, order2 = exchange_marks([[], [5, 2], [3]], [0, 1, 2])
+    assert marks2 == {"1": [5, 2], "2": [3]} and order2 == [2, 1, 0]
+    # (4) single-stream issue (MTBT_TRAIN_LANES=0): one event after the highest marked index covers everything (stream order)
+    monkeypatch.setenv("MTBT_LANES", "1")
+    bwd.reload_env()
+    s1 = bwd.schedule()
+    assert set(s1.lane) == {0} and all(bwd.mark_points(s1, marks)[str(b)] == [max(writers[b])] for b in live)
+
+
+def test_snapshot_views_are_fresh_copies():
+    """FlatBuckets.snapshot_views: what the autograd node of forward(x, "train") hands out -- views into ONE fresh copy per bucket."""
+    shapes = [("a", (4, 3)), ("b", (5,)), ("c", (2, 2, 2)), ("d", (7,))]
+    fb = FlatBuckets(shapes, "cpu", bucket_bytes=64)
+    for i, (n, _) in enumerate(shapes):
+        fb.views[n].fill_(float(i + 1))
+    snap = fb.snapshot_views(["a", "c", "d"])
+    own = {b.untyped_storage().data_ptr() for b in fb.buckets}
+    assert set(snap) == {"a", "c", "d"}
+    for n, v in snap.items():
+        assert tuple(v.shape) == dict(shapes)[n] and torch.equal(v, fb.views[n]) and v.untyped_storage().data_ptr() not in own
+    fb.zero_()
+    assert float(snap["c"].sum()) == 8 * 3.0                       # the snapshot does not follow the arena
+    same_bucket = [n for n in snap if fb.where[n][0] == fb.where["a"][0]]
+    assert len({snap[n].untyped_storage().data_ptr() for n in same_bucket}) == 1   # one copy per bucket, not per tensor

@@ -66,3 +66,54 @@ def test_matches_loop_oracle_on_random_sets():
         assert set(got) == set(want)
         for k in want:
             assert abs(got[k] - want[k]) < 1e-12, (trial, k, got[k], want[k])
+
+
+def test_gloo_world_size_2_metric_sync(tmp_path):
+    """Data-parallel validation (configs[3]): the reference's metrics are `dist_sync_on_step=True` (running_main_v3.py:193-218) -- every
+    rank's state is gathered before compute.  Two gloo ranks hold DIFFERENT images; `compute()` on each returns the value one process
+    holding all images (in rank order) computes, for the box mAP and for the segmentation counts; the local state is untouched."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, json, numpy as np, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from multitask_bonetumor_yolo_amd.metrics import MeanAveragePrecision, SegmentationMetrics\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "def images(rank):\n"
+        "    rng = np.random.default_rng(100 + rank)\n"
+        "    P, T = [], []\n"
+        "    for _ in range(5 + rank):\n"
+        "        G, D = int(rng.integers(1, 4)), int(rng.integers(0, 9))\n"
+        "        gb = np.concatenate([rng.uniform(0, 80, (G, 2)), rng.uniform(8, 30, (G, 2))], 1); gb[:, 2:] += gb[:, :2]\n"
+        "        db = gb[rng.integers(0, G, D)] + rng.normal(0, 3.0, (D, 4))\n"
+        "        P.append(dict(boxes=db, scores=np.round(rng.uniform(0, 1, D), 2), labels=rng.integers(0, 2, D)))\n"
+        "        T.append(dict(boxes=gb, labels=rng.integers(0, 2, G)))\n"
+        "    return P, T\n"
+        "def counts(rank):\n"
+        "    g = torch.Generator().manual_seed(7 + rank)\n"
+        "    return torch.randint(0, 500, (3 + rank, 4), generator=g), torch.rand(3 + rank, generator=g) * 100\n"
+        "m = MeanAveragePrecision(); m.update(*images(r)); n_local = len(m._images)\n"
+        "got = m.compute()\n"
+        "ref = MeanAveragePrecision(dist_sync=False)\n"
+        "for k in range(w): ref.update(*images(k))\n"
+        "want = ref.compute()\n"
+        "assert got == want and len(m._images) == n_local, (got, want)\n"
+        "local = MeanAveragePrecision(dist_sync=False); local.update(*images(r))\n"
+        "assert local.compute() != want          # the rank-local value (what round 2 reported) is a different number\n"
+        "s = SegmentationMetrics(); c, p = counts(r); s._counts.append(c); s._psum.append(p)\n"
+        "gs = s.compute()\n"
+        "rs = SegmentationMetrics(dist_sync=False)\n"
+        "for k in range(w):\n"
+        "    c, p = counts(k); rs._counts.append(c); rs._psum.append(p)\n"
+        "assert gs == rs.compute() and len(s._counts) == 1\n"
+        "print(f'RANK{r} ok {got[\"map\"]:.6f} {gs[\"iou\"]:.6f}', flush=True)\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    rows = sorted(l.split() for o in outs for l in o.splitlines() if l.startswith("RANK"))
+    assert len(rows) == 2 and rows[0][1:] == rows[1][1:]          # both ranks: the same global numbers

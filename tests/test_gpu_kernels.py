@@ -326,3 +326,29 @@ def test_convnext_mlp_fused(D, M):
     err = (y.float().cpu() - ref).abs().max().item()
     assert err < 0.03 * max(1.0, ref.abs().max().item()), err   # bf16 output rounding (2^-8 relative) dominates
     assert ((y.float().cpu() - ref).norm() / ref.norm()).item() < 5e-3
+
+
+def test_fp16_store_saturates_and_keeps_nan():
+    """The fp16 arithmetic mode's stores (common.h f2h_bits, BASELINE configs[4]): finite values beyond the binary16 range saturate at
+    +-65504, infinities too, and a NaN stays a NaN (v_med3_f32 alone would have returned -65504 for it and hidden a divergence)."""
+    lib = L.load()
+    src = torch.tensor([float("nan"), float("inf"), float("-inf"), 1.0e6, -1.0e6, 65504.0, 1.0, -2.5, 0.0, 70000.0, -float("nan"), 3.0e-8] * 16,
+                       dtype=torch.float32, device=DEV)
+    dst = torch.zeros(src.numel(), dtype=torch.float16, device=DEV)
+    L.check(lib.mtbt_cast(src.data_ptr(), dst.data_ptr(), src.numel(), L.F32, L.F16, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "cast")
+    torch.cuda.synchronize()
+    got = dst.float().cpu()[:12]
+    want = torch.tensor([float("nan"), 65504.0, -65504.0, 65504.0, -65504.0, 65504.0, 1.0, -2.5, 0.0, 65504.0, float("nan"), 0.0])
+    assert torch.isnan(got[0]) and torch.isnan(got[10])
+    fin = [i for i in range(12) if i not in (0, 10)]
+    assert torch.equal(got[fin][:-1], want[fin][:-1]) and abs(got[11].item() - 3.0e-8) < 6e-8   # (3e-8 is a binary16 subnormal: rounded, not flushed to garbage)
+    # the conv epilogue's fp16 store takes the same path: a NaN input pixel stays visible in the output
+    p = Plan(DEV)
+    x = torch.zeros(1, 4, 4, 32, dtype=torch.float16, device=DEV)
+    x[0, 1, 2, 3] = float("nan")
+    w = torch.eye(32, dtype=torch.float16, device=DEV)
+    y = p.new(1, 4, 4, 32, L.F16)
+    p.conv(Act.of(x), w, y, name="nan probe")
+    run(p)
+    out = y.buf.float().cpu()
+    assert torch.isnan(out[0, 1, 2]).all() and not torch.isnan(out[0, 0]).any()

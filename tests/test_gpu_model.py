@@ -452,6 +452,48 @@ def test_infer_bf16_at_640_per_output_bounds(pair):
     assert (d16["best_score"] - d32["best_score"]).abs().max().item() <= 0.03
 
 
+def test_bf16_post_process_agrees_with_fp32_on_calibrated_heads():
+    """The cross-precision check of what the benchmark's post-process produces (running_main_v3.py:535-552 on the model's own outputs):
+    synthetic heads calibrated so that ~10^3 of the 8400 anchors pass conf 0.05 with scores spread over (0.01, 0.99) (SURVEY 8d;
+    `calibrate_synthetic_heads_`).  The boxes NMS keeps in bf16 and in fp32 arithmetic then agree: >= 90 % of the bf16 boxes have an
+    fp32 box of IoU >= 0.9 (and vice versa), and the COCO mAP@0.5 of the bf16 detections against the fp32 detections taken as ground
+    truth is >= 0.95.  (Round 2 dropped this check: with every score at ~0.5 the top-100 set was decided below bf16's resolution.)"""
+    from multitask_bonetumor_yolo_amd import MeanAveragePrecision, calibrate_synthetic_heads_, init_synthetic_
+    from multitask_bonetumor_yolo_amd.metrics import box_iou_xyxy
+    torch.manual_seed(77)
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval()
+    S, B = 640, 4
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(78)).to(DEV)
+    hip.set_compute_dtype(torch.float32)
+    calibrate_synthetic_heads_(hip, x)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        hip.set_compute_dtype(dt)
+        _, det = hip.infer_and_detect(x, S, masks=False)
+        torch.cuda.synchronize()
+        res[dt] = {k: det[k].cpu() for k in ("boxes", "scores", "labels", "counts", "n_cand")}
+    hip.set_compute_dtype(torch.float32)
+    r32, r16 = res[torch.float32], res[torch.bfloat16]
+    nc = r32["n_cand"].float()
+    assert 300 <= nc.mean().item() <= 3000, nc                              # a real confidence filter: neither "all 8400" nor "none"
+    sc = torch.cat([r32["scores"][b, :int(r32["counts"][b])] for b in range(B)])
+    assert sc.max().item() > 0.6 and sc.min().item() < 0.5                  # spread scores, not a band around 0.5
+    hit = tot = 0
+    preds, targets = [], []
+    for b in range(B):
+        n32, n16 = int(r32["counts"][b]), int(r16["counts"][b])
+        assert n32 > 0 and n16 > 0
+        iou = box_iou_xyxy(r16["boxes"][b, :n16].numpy(), r32["boxes"][b, :n32].numpy())
+        hit += int((iou.max(axis=1) >= 0.9).sum()) + int((iou.max(axis=0) >= 0.9).sum())
+        tot += n16 + n32
+        preds.append(dict(boxes=r16["boxes"][b, :n16], scores=r16["scores"][b, :n16], labels=r16["labels"][b, :n16]))
+        targets.append(dict(boxes=r32["boxes"][b, :n32], labels=r32["labels"][b, :n32]))
+    assert hit / tot >= 0.9, hit / tot
+    m = MeanAveragePrecision([0.5], [1, 10, 100], dist_sync=False)
+    m.update(preds, targets)
+    assert m.compute()["map_50"] >= 0.95, m.compute()
+
+
 def test_infer_fp16_at_1280_vs_oracle(pair):
     """BASELINE configs[4]'s arithmetic and shape: fp16 storage, v_mfma_f32_16x16x32_f16, 1280 x 1280.  fp16 keeps 11 mantissa bits (8x
     bf16's resolution) inside +-65504: outputs within 1 % of each output's range / 5e-3 relative L2 of the fp32 oracle; the NMS kept
@@ -482,28 +524,38 @@ def test_infer_fp16_at_1280_vs_oracle(pair):
 def test_infer_fp16_batch64_1280_properties():
     """configs[4] at full size (batch 64, 1280 x 1280, fp16) through size-independent properties: every output finite, every image's result
     identical to the same image run in a batch of 4 (images are independent: no cross-image arithmetic, tile order does not change a
-    pixel's reduction order), kept boxes sorted by score, inside the image, at most top-k."""
-    from multitask_bonetumor_yolo_amd import init_synthetic_
+    pixel's reduction order), kept boxes sorted by score, inside the image, at most top-k; the instance masks (64 x 100 x 1280^2 booleans,
+    10.5 GB) of the full batch equal those of the 4-image runs bit for bit and are empty beyond each image's kept count."""
+    from multitask_bonetumor_yolo_amd import calibrate_synthetic_heads_, init_synthetic_
     torch.manual_seed(64)
     hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.float16)
     S, B = 1280, 64
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(65)).to(DEV)
-    fwd, det = hip.infer_and_detect(x, S, masks=False)
+    calibrate_synthetic_heads_(hip, x[:2].contiguous())
+    fwd, det = hip.infer_and_detect(x, S, masks=True)
     big = {k: v.clone() for k, v in _out_list(fwd).items()}
-    kept = {k: det[k].clone() for k in ("keep_idx", "counts", "boxes", "scores")}
+    kept = {k: det[k].clone() for k in ("keep_idx", "counts", "boxes", "scores", "n_cand")}
+    masks = det["masks"]
     torch.cuda.synchronize()
+    assert masks.shape == (B, 100, S, S) and masks.dtype == torch.bool
     for k, v in big.items():
         assert torch.isfinite(v).all(), k
     for lo in (0, 60):
-        fs, ds = hip.infer_and_detect(x[lo:lo + 4].contiguous(), S, masks=False)
+        fs, ds = hip.infer_and_detect(x[lo:lo + 4].contiguous(), S, masks=True)
         small = _out_list(fs)
         torch.cuda.synchronize()
         for k, v in small.items():
             assert torch.equal(v, big[k][lo:lo + 4]), (k, lo)
         assert torch.equal(ds["keep_idx"], kept["keep_idx"][lo:lo + 4]) and torch.equal(ds["counts"], kept["counts"][lo:lo + 4])
+        assert torch.equal(ds["masks"], masks[lo:lo + 4]), ("masks", lo)
     cnt = kept["counts"].cpu()
     assert int(cnt.max()) <= 100 and int(cnt.sum()) > 0
+    ncand = kept["n_cand"].cpu()
+    assert int(ncand.min()) > 0 and int(ncand.max()) < 33600          # calibrated heads: a real confidence filter, not "every anchor"
     for n in range(B):
         c = int(cnt[n])
         sc, bx = kept["scores"][n, :c].cpu(), kept["boxes"][n, :c].cpu()
         assert torch.all(sc[:-1] >= sc[1:]) and bx.min().item() >= 0 and bx.max().item() <= S
+        if c < 100:
+            assert not masks[n, c:].any()
+    assert masks[:, 0].any()

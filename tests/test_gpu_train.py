@@ -289,14 +289,159 @@ def test_training_plans_on_lanes_are_bit_identical(monkeypatch):
             for n, b in hip.named_buffers():
                 b.copy_(bufs[n])
     monkeypatch.setenv("MTBT_TRAIN_LANES", "0")
+    ts.tp.reload_env()                                   # (the lane knobs are read once per plan)
     ts.forward_backward(x, gt_boxes, gt_masks, gt_cls)
     torch.cuda.synchronize()
     ref = [b.clone() for b in ts.grads.buckets]
     monkeypatch.setenv("MTBT_TRAIN_LANES", "1")
     monkeypatch.setenv("MTBT_LANES", "4")
+    ts.tp.reload_env()
     for _ in range(6):
         reset()
         ts.forward_backward(x, gt_boxes, gt_masks, gt_cls)
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(zip(ref, ts.grads.buckets)):
             assert torch.equal(a, b), f"gradient bucket {i} differs between single-stream and lane execution"
+
+
+def test_gradient_accumulation_over_two_backward_passes_fp32():
+    """Two forward + backward passes WITHOUT zero_grad (gradient accumulation, `zero_grad(set_to_none=False)`): `.grad` = g1 + g2 as with
+    autograd through the oracle.  The autograd node hands out views of fresh per-backward copies of the gradient buckets; round 2 handed
+    out views of the persistent arena, which AccumulateGrad keeps as `.grad` without a copy where the strides match (stem weight, 1x1
+    depthwise weights, class bias): the second pass then rewrote `.grad` in place and added the buffer to itself (2*g2)."""
+    ora, hip = build("main", seed=3)
+    g = torch.Generator().manual_seed(23)
+    xs = [torch.rand(2, 3, 64, 64, generator=g) for _ in range(2)]
+    first = {}
+    for k, x in enumerate(xs):
+        ro = flat_outputs(ora(x, "train"))
+        ho = flat_outputs(hip(x.to(DEV), "train"))
+        probes = [torch.randn(r.shape, generator=g) / r[0].numel() ** 0.5 for r in ro]
+        sum((r * w).sum() for r, w in zip(ro, probes)).backward()
+        sum((h * w.to(DEV)).sum() for h, w in zip(ho, probes)).backward()
+        torch.cuda.synchronize()
+        if k == 0:
+            first = {n: (p.grad, p.grad.clone()) for n, p in hip.named_parameters() if p.grad is not None}
+    compare_grads(ora, hip, 1e-3, "accumulated over two passes")
+    # a `.grad` tensor saved after the first pass is never a window onto memory the second pass rewrites: autograd accumulated into it
+    # (in place), so it now holds g1 + g2 and differs from its own first-pass value by exactly the oracle's second-pass gradient
+    tp = next(iter(hip._train_plans.values()))
+    arena = {b.untyped_storage().data_ptr() for b in tp.arena.buckets}
+    for n, p in hip.named_parameters():
+        if p.grad is not None:
+            assert p.grad.untyped_storage().data_ptr() not in arena, f"{n}.grad aliases the persistent gradient arena"
+    for n in ("backbone.body.stem_0.weight", "neck.bifpn_units.0.p4_td_conv.depthwise.weight", "detect.cv3.0.2.bias"):
+        kept, old = first[n]
+        assert kept is dict(hip.named_parameters())[n].grad and not torch.equal(kept, old)
+
+
+def test_forward_follows_the_trainers_autocast():
+    """`precision="bf16-mixed"` (running_main_v3.py:825): Lightning wraps forward in autocast("cuda", bfloat16).  A drop-in whose arithmetic
+    mode was never pinned follows it -- the bf16 training / inference plans are the ones lowered and run, the outputs stay fp32 tensors, the
+    backward works outside the autocast region (as Lightning calls it) -- and a pinned mode is not overridden."""
+    ora, hip = build("main", seed=4)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(31)).to(DEV)
+    assert hip.compute_dtype == torch.float32
+    with torch.autocast("cuda", torch.bfloat16):
+        assert hip.compute_dtype == torch.bfloat16
+        det, (seg, mc, protos), logits = hip(x, "train")
+        loss = sum(d.float().mean() for d in det) + protos.float().mean() + logits.float().sum()
+    assert all(t.dtype == torch.float32 for t in list(det) + [mc, protos, logits])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert [k[1] for k in hip._train_plans] == [torch.bfloat16]
+    g16 = {n: p.grad.float().clone() for n, p in hip.named_parameters() if p.grad is not None}
+    assert g16 and all(torch.isfinite(g).all() for g in g16.values())
+    hip.zero_grad(set_to_none=True)
+    det, (seg, mc, protos), logits = hip(x, "train")                      # outside autocast: the fp32 parity mode, a second plan
+    (sum(d.mean() for d in det) + protos.mean() + logits.sum()).backward()
+    torch.cuda.synchronize()
+    assert sorted(str(k[1]) for k in hip._train_plans) == ["torch.bfloat16", "torch.float32"]
+    name = "backbone.c2f_p3.cv2.conv.weight"
+    g32 = dict(hip.named_parameters())[name].grad.float()
+    assert (g16[name] - g32).norm().item() <= 0.1 * g32.norm().item()      # the same gradient in bf16 arithmetic
+    hip.eval()
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        out = hip(x, "infer")
+    assert out["img_cls_logits"].dtype == torch.float32 and any(k[1] == torch.bfloat16 for k in hip._plans)
+    hip.set_compute_dtype(torch.float32)
+    with torch.no_grad(), torch.autocast("cuda", torch.bfloat16):
+        assert hip.compute_dtype == torch.float32                          # pinned: autocast is not consulted
+    with torch.autocast("cuda", torch.float16):
+        hip.set_compute_dtype(None).train()
+        with pytest.raises(NotImplementedError):
+            hip(x, "train")                                                # fp16 is an inference mode
+
+
+def test_two_rank_overlapped_exchange_is_bit_identical_to_sequential(tmp_path):
+    """configs[3]'s exchange at a size where the backward plan really spreads over its four lanes (2 ranks x 4 x 256^2, bf16, MTBT_TRAIN_LANES=1):
+    with the bucket all-reduces OVERLAPPED with backward (side stream, one event per writer lane) the parameters after two steps are
+    bit-identical to the run that reduces after the whole backward pass.  A collective that started before one of its bucket's writers had
+    finished (round 2's single-event wait) shows up here as a difference."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for overlap in ("1", "0"):
+        out = str(tmp_path / f"ddp_{overlap}.pt")
+        env = dict(os.environ, MTBT_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MTBT_DDP_OVERLAP=overlap,
+                   MTBT_DDP_S="256", MTBT_DDP_PER="4", MTBT_DDP_DTYPE="bf16", MTBT_TRAIN_LANES="1", MTBT_LANES="4")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29537", os.path.join(root, "tools", "ddp_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs[overlap] = torch.load(out, weights_only=True)
+    a, b = outs["1"], outs["0"]
+    assert all(torch.isfinite(t).all() for t in a["buckets"])
+    for i, (u, v) in enumerate(zip(a["buckets"], b["buckets"])):
+        assert torch.equal(u, v), f"parameter bucket {i}: overlapped exchange != sequential exchange (max diff {(u - v).abs().max().item():.3e})"
+    assert torch.equal(a["proj"], b["proj"]) and all(torch.equal(x, y) for x, y in zip(a["losses"], b["losses"]))
+
+
+def test_train_step_at_configs2_size_bf16(monkeypatch):
+    """BASELINE configs[2] at its real size -- ONE `TrainStep.step` of batch 32 x 640^2 in bf16 (SGD, clip 10): the 20.8 GiB activation arena,
+    the 1024-workgroup weight-gradient splits and the batch-32 tile choices, through size-independent properties: finite loss and gradient
+    norm, positives found, every reduced gradient bucket finite and non-zero, and the gradients of the 4-lane execution bit-identical
+    to single-stream execution of the same plans."""
+    import os
+    import sys
+    from multitask_bonetumor_yolo_amd import init_synthetic_
+    from multitask_bonetumor_yolo_amd.trainstep import TrainStep
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_targets
+    torch.manual_seed(0)
+    B, S = 32, 640
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).set_compute_dtype(torch.bfloat16)
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(0)).to(DEV)
+    boxes, masks, cls = synthetic_targets(B, S, 0, torch.device(DEV))
+    monkeypatch.setenv("MTBT_TRAIN_LANES", "1")
+    monkeypatch.setenv("MTBT_LANES", "4")
+    ts = TrainStep(hip, (B, 3, S, S), optimizer="sgd", lr=1e-4, iou_match_thresh=0.05)
+    assert ts.tp.fwd.pool.bytes > 15 * 2 ** 30                                  # the kept activations of the real configuration
+    bufs = {n: b.clone() for n, b in hip.named_buffers()}
+    ts.forward_backward(x, boxes, masks, cls)
+    torch.cuda.synchronize()
+    lanes = [b.clone() for b in ts.grads.buckets]
+    with torch.no_grad():
+        for n, b in hip.named_buffers():
+            b.copy_(bufs[n])                                                     # (the column sums are taken about the running mean)
+    monkeypatch.setenv("MTBT_TRAIN_LANES", "0")
+    ts.tp.reload_env()
+    ts.forward_backward(x, boxes, masks, cls)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(lanes, ts.grads.buckets)):
+        assert torch.equal(a, b), f"gradient bucket {i}: lanes != single stream at batch 32 x 640^2"
+    monkeypatch.setenv("MTBT_TRAIN_LANES", "1")
+    ts.tp.reload_env()
+    before = [b.clone() for b in ts.params.buckets]
+    loss = ts.step(x, boxes, masks, cls)
+    torch.cuda.synchronize()
+    lv = loss.float().cpu()
+    assert torch.isfinite(lv).all() and lv[6].item() > 0, lv                     # total ... #positives > 0
+    assert torch.isfinite(ts.gnorm).all() and ts.gnorm.item() > 0
+    for i in range(ts.n_skip, len(ts.grads.buckets)):
+        g = ts.grads.buckets[i]
+        assert torch.isfinite(g).all() and g.abs().max().item() > 0, f"gradient bucket {i}"
+        assert not torch.equal(before[i], ts.params.buckets[i]), f"parameter bucket {i} did not move"
+    for i in range(ts.n_skip):
+        assert torch.equal(before[i], ts.params.buckets[i])                      # Segment cv2 / cv3 / cv4: never stepped (SURVEY F13)

@@ -46,8 +46,9 @@ if __name__ == "__main__":
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     from multitask_bonetumor_yolo_amd.trainstep import TrainStep
-    S, per = 128, 2
+    S, per = int(os.environ.get("MTBT_DDP_S", "128")), int(os.environ.get("MTBT_DDP_PER", "2"))
     model = build_model(dev)
+    model.set_compute_dtype({"f32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("MTBT_DDP_DTYPE", "f32")])
     torch.manual_seed(3)
     proj = torch.nn.Conv2d(32, 1, 1)
     ts = TrainStep(model, (per, 3, S, S), projector=proj, overlap=os.environ.get("MTBT_DDP_OVERLAP", "1") == "1", **STEP_KW)

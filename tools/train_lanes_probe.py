@@ -20,6 +20,7 @@ for name, plan in (("fwd", ts.tp.fwd), ("bwd", ts.bwd)):
 for rnd in range(2):
     for lanes in ("0", "1"):
         os.environ["MTBT_TRAIN_LANES"] = lanes
+        ts.tp.reload_env()
         for _ in range(2):
             ts.step(x, boxes, masks, cls)
         torch.cuda.synchronize(); t0 = time.perf_counter()
