@@ -57,7 +57,7 @@ extern "C" {
 #define MTBT_ABI_VERSION 3
 int mtbt_abi_version(void);
 /* sizeof() of the argument structs as the LIBRARY was compiled: which = 0 mtbt_conv_args, 1 mtbt_fuse_args, 2 mtbt_decode_args,
- * 3 mtbt_mask_args, 4 mtbt_loss_args, 5 mtbt_prep_desc, 6 mtbt_raw_image; -1 for any other value.  A binding compares them with its
+ * 3 mtbt_mask_args, 4 mtbt_loss_args, 5 mtbt_prep_desc, 6 mtbt_raw_image, 7 mtbt_upconv_args, 8 mtbt_node_args; -1 for any other value.  A binding compares them with its
  * own layout at load time (a stale prebuilt .so would otherwise read pointers from the wrong offsets). */
 int mtbt_sizeof_args(int which);
 /* "gfx950" */
@@ -168,6 +168,24 @@ typedef struct mtbt_fuse_args {
 } mtbt_fuse_args;
 
 int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream);
+
+/* The whole BiFPN node in one launch (inference, 16-bit storage): the weighted sum above as the B-operand staging of the
+ * DepthwiseConvBlock's 1x1 GEMM (main_model.py:62-102: depthwise k = 1 scale folded into the pointwise weight, BatchNorm folded, ELU):
+ *   y[p][k] = act( sum_c w[k][c] * fuse(p)[c] + shift[k] )
+ * fuse.y is ignored (the fused map never reaches memory; it is rounded to the storage type exactly as mtbt_bifpn_fuse stores it, so the
+ * result equals the two-launch form up to the GEMM's accumulation order).  K == fuse.C in {128, 256}, fuse.dtype MTBT_BF16 | MTBT_F16,
+ * add_weight_bug must be 0; the inputs' modes must be (identity, bilinear x2) or (identity, identity, 2x2 mean) -- the two node shapes of
+ * BiFPNUnit.forward; anything else returns MTBT_EINVAL (use mtbt_bifpn_fuse + mtbt_conv2d_nhwc).  y [N,H,W,K] NHWC with pixel stride y_pixel_stride (batch stride H*W*y_pixel_stride). */
+typedef struct mtbt_node_args {
+  mtbt_fuse_args fuse;
+  const void* w;       /* [K][C] dtype */
+  const float* shift;  /* [K] */
+  void* y;
+  int32_t y_pixel_stride;
+  int32_t K;
+  int32_t act;         /* MTBT_ACT_NONE .. MTBT_ACT_GELU_POLY */
+} mtbt_node_args;
+int mtbt_bifpn_node_nhwc(const mtbt_node_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm2d forward with BATCH statistics + activation (module in train mode): the reference flips the
@@ -304,6 +322,32 @@ int mtbt_multitask_loss(const mtbt_loss_args* a, void* stream);
  * the DFL targets carry no gradient, exactly as in autograd. */
 int mtbt_multitask_loss_grad(const mtbt_loss_args* a, float* const* d_map, const int32_t* d_map_pixel_stride, float* d_seg_logits,
                              float* d_img_logits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ConvTranspose2d(C, Cm, 2, stride 2, bias) -> Conv 3x3 (Cm -> K, pad 1) + per-channel shift + activation as ONE direct convolution
+ * over the LOW-resolution map (inference).  Replaces ultralytics `Proto.upsample` followed by `Proto.cv2` (conv + folded BatchNorm +
+ * SiLU): main_model.py:326-328 [ultralytics Proto], SURVEY 8a row 10.  Both operators are linear with nothing in between: per output
+ * parity q = 2 * (Y & 1) + (X & 1) the pair is a 2 x 2-tap convolution of the source map with composed weights (4/10 of the MACs; the
+ * upsampled tensor is never written).
+ *   x [N,H,W,C] dtype NHWC (H % 16 == 0, W % 16 == 0);  y [N,2H,2W,K] dtype (K % 128 == 0)
+ *   w [4][K][2][2][C] dtype:  w[q][k][rho][sigma][ci] multiplies source pixel (i + a - 1 + rho, j + b - 1 + sigma), a = q >> 1, b = q & 1,
+ *       for output pixel (2i + a, 2j + b) (zero outside the source map)
+ *   shift [9][K] f32: shift[rc * 3 + cc][k], rc / cc = border class of the OUTPUT row / column: 0 = first, 2 = last, 1 = interior
+ *       (the transposed conv's bias enters through the taps that lie inside the upsampled map only: the 3x3 conv pads with zeros)
+ *   y = act(conv2x2_q(x) + shift[class])           act: MTBT_ACT_NONE | MTBT_ACT_SILU
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtbt_upconv_args {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* shift;
+  int64_t x_batch_stride, y_batch_stride; /* elements */
+  int32_t x_pixel_stride, y_pixel_stride; /* elements */
+  int32_t N, H, W, C, K;
+  int32_t dtype; /* MTBT_F32 | MTBT_BF16 | MTBT_F16: x, w, y */
+  int32_t act;
+} mtbt_upconv_args;
+int mtbt_convt2x2_conv3x3_nhwc(const mtbt_upconv_args* a, void* stream);
 
 /* Fused ConvNeXt MLP (timm Mlp fc1 -> GELU -> fc2 with the layer-scale folded, + residual) for d in {96, 192}, bf16 only:
  *   y[p][:] = res[p][:] + W2' . GELU(W1 . t[p][:] + b1) + b2'      (the 4d-wide hidden tensor never leaves the chip)

@@ -13,4 +13,4 @@ from .loss import multitask_loss  # noqa: F401
 from .checkpoints import load_pretrained_heads, strip_lightning_prefix  # noqa: F401
 from .graphed import GraphedInference  # noqa: F401
 from .metrics import MeanAveragePrecision, SegmentationMetrics  # noqa: F401
-from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv0, ConvNeXtBiFPNYOLOv2, calibrate_synthetic_heads_, init_synthetic_  # noqa: F401
+from .model import ConvNeXtBiFPNYOLO, ConvNeXtBiFPNYOLOv0, ConvNeXtBiFPNYOLOv2, calibrate_synthetic_heads_, init_synthetic_, synthetic_images  # noqa: F401

@@ -39,6 +39,17 @@ class FuseArgs(C.Structure):
     ]
 
 
+class NodeArgs(C.Structure):  # mtbt_node_args
+    _fields_ = [("fuse", FuseArgs), ("w", C.c_void_p), ("shift", C.c_void_p), ("y", C.c_void_p), ("y_pixel_stride", C.c_int32), ("K", C.c_int32),
+                ("act", C.c_int32)]
+
+
+class UpconvArgs(C.Structure):  # mtbt_upconv_args
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("shift", C.c_void_p),
+                ("x_batch_stride", C.c_int64), ("y_batch_stride", C.c_int64), ("x_pixel_stride", C.c_int32), ("y_pixel_stride", C.c_int32),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("dtype", C.c_int32), ("act", C.c_int32)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [
         ("map", C.c_void_p * 3), ("h", C.c_int32 * 3), ("w", C.c_int32 * 3), ("map_pixel_stride", C.c_int32 * 3),
@@ -89,11 +100,13 @@ SYMBOLS = {
     "mtbt_sizeof_args": (C.c_int, [C.c_int]),
     "mtbt_target_arch": (C.c_char_p, []),
     "mtbt_conv2d_nhwc": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "mtbt_convt2x2_conv3x3_nhwc": (C.c_int, [C.POINTER(UpconvArgs), C.c_void_p]),
     "mtbt_stem_conv4x4_ln": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "mtbt_dwconv_nhwc": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
                          + [C.c_int] * 6 + [C.c_void_p]),
     "mtbt_layernorm_nhwc": (C.c_int, [C.c_void_p] * 3 + [C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_bifpn_fuse": (C.c_int, [C.POINTER(FuseArgs), C.c_void_p]),
+    "mtbt_bifpn_node_nhwc": (C.c_int, [C.POINTER(NodeArgs), C.c_void_p]),
     "mtbt_bn_train_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "mtbt_bn_train_nhwc": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int64, C.c_void_p]),
@@ -168,7 +181,7 @@ SYMBOLS = {
     "mtbt_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 
-ARG_STRUCTS = (ConvArgs, FuseArgs, DecodeArgs, MaskArgs, LossArgs, PrepDesc, RawImage)   # order of mtbt_sizeof_args(which)
+ARG_STRUCTS = (ConvArgs, FuseArgs, DecodeArgs, MaskArgs, LossArgs, PrepDesc, RawImage, UpconvArgs, NodeArgs)   # order of mtbt_sizeof_args(which)
 _lib = None
 
 

@@ -52,6 +52,17 @@ __device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x) {
 // 64-byte-row swizzle of conv_igemm.inc (CPR = 4)
 __device__ __forceinline__ int swz4(int row) { return (-(row >> 2)) & 3; }
 
+// development ablation bits of the resident kernel: compiled in only with -DMTBT_MLP_ABLATION (tools/probes/mlp_variants.hip)
+#ifdef MTBT_MLP_ABLATION
+#define MLP_ABL(p, bit) ((p).dbg & (bit))
+#else
+#define MLP_ABL(p, bit) 0
+#endif
+
+#ifndef MTBT_MLP_RESIDENT
+#define MTBT_MLP_RESIDENT 0     // 1: d = 96 calls of >= 64 K pixels take the weight-resident persistent kernel (measured slower so far)
+#endif
+
 struct MlpP {
   const bf16_t* t;     // [M][D] fc1 input (LayerNorm output)
   const bf16_t* w1;    // [4D][D]
@@ -73,7 +84,12 @@ template <> __device__ __forceinline__ f32x4 unpack4<bf16_t>(uint2 r) {
 }
 template <> __device__ __forceinline__ f32x4 unpack4<f16_t>(uint2 r) { return f32x4{h_lo(r.x), h_hi(r.x), h_lo(r.y), h_hi(r.y)}; }
 
-template <int D, int FP, int WPS, typename HT>
+// PIPE (wide d, few waves per SIMD): inside a chunk the wave's two pixel blocks run as a two-stage pipeline -- GEMM1(block 0), then GEMM1(block 1)
+// NEXT TO the GELU of block 0 (independent: the matrix pipe and the VALU overlap, hipcc interleaves them when they are in one
+// scheduling region), the GELU of block 1, GEMM2 of both.  The unpipelined order is GEMM1 -> GELU -> GEMM2 with nothing beside the
+// GELU's ~130 VALU instructions, and at one wave per SIMD (d = 384) no other wave fills that hole (ISA of round 2: 96 MFMAs, then 260
+// VALU, then 96 MFMAs per chunk).  The chunk's W1 fragments stay in registers for both blocks (one LDS read per two MFMAs as before).
+template <int D, int FP, int WPS, typename HT, bool PIPE = false>
 __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   constexpr int KS1 = D / 32;            // k-steps of GEMM1
   constexpr int FC = D / 16;             // output-channel fragments of GEMM2
@@ -174,6 +190,78 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
       // bias of this chunk's 32 hidden units: rows 4 lq .. +3 of block a and of block b
       const float4 ba = *reinterpret_cast<const float4*>(b1s + jj * 32 + lq * 4);
       const float4 bb = *reinterpret_cast<const float4*>(b1s + jj * 32 + 16 + lq * 4);
+      if constexpr (PIPE) {
+        static_assert(FP == 2, "two pixel blocks per wave");
+        // a lane's 4 hidden units of one 16-row block -> bias + GELU -> two packed pairs (half of GEMM2's B fragment)
+        auto gelu_half = [&](const f32x4& hv, const float4& bv, uint32_t& lo, uint32_t& hi) {
+          f32x2_t a01 = f32x2_t{hv[0] + bv.x, hv[1] + bv.y}, a23 = f32x2_t{hv[2] + bv.z, hv[3] + bv.w};
+          a01 = gelu_poly2(a01); a23 = gelu_poly2(a23);
+          lo = pk2<HT>(a01.x, a01.y); hi = pk2<HT>(a23.x, a23.y);
+        };
+        uint4 hb0, hb1;
+        f32x4 h0a = f32x4{0.f, 0.f, 0.f, 0.f}, h0b = h0a, h1a = h0a, h1b = h0a;
+        {   // region 1: hidden rows 0..15 of the chunk ("a" block of W1) for both pixel blocks
+          uint4 wa[KS1];
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) wa[ks] = *reinterpret_cast<const uint4*>(st + a1off[ks]);
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) {
+            h0a = mfma_16x16x32<HT>(wa[ks], tf[0][ks], h0a);
+            h1a = mfma_16x16x32<HT>(wa[ks], tf[1][ks], h1a);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, KS1, 0);      // all twelve fragment reads in flight, then the MFMAs as they land
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * KS1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (the "a" accumulators become visible HERE: without this the GELU below -- pure arithmetic, free to float in the DAG -- is emitted
+        //  above the scheduling barrier, behind the last MFMAs of region 1, and nothing is left to put beside region 2's MFMAs)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { asm volatile("" : "+v"(h0a[e])); asm volatile("" : "+v"(h1a[e])); }
+        {   // region 2: hidden rows 16..31 ("b" block) beside the GELU of the "a" rows: one MFMA, then up to three VALU instructions
+          uint4 wb[KS1];
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) wb[ks] = *reinterpret_cast<const uint4*>(st + a1off[ks] + 1024);
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) {
+            h0b = mfma_16x16x32<HT>(wb[ks], tf[0][ks], h0b);
+            h1b = mfma_16x16x32<HT>(wb[ks], tf[1][ks], h1b);
+          }
+          gelu_half(h0a, ba, hb0.x, hb0.y);
+          gelu_half(h1a, ba, hb1.x, hb1.y);
+          // schedule of the region: all fragment reads first, a few GELU instructions while they fly, then one MFMA and up to three VALU
+          // instructions, 2 * KS1 times (the GELU rides in the issue slots the MFMAs leave: ~66 VALU for 24 MFMAs)
+          __builtin_amdgcn_sched_group_barrier(0x100, KS1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+#pragma unroll
+          for (int g = 0; g < 2 * KS1; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // region 3: GELU of the "b" rows (nothing to put beside it inside this chunk), then GEMM2 of both blocks: one weight fragment, two
+        // MFMAs, the fragments requested PD steps ahead (left to itself hipcc reads a fragment, waits, issues its two MFMAs)
+        gelu_half(h0b, bb, hb0.z, hb0.w);
+        gelu_half(h1b, bb, hb1.z, hb1.w);
+        constexpr int PD = 4;
+        uint4 w2q[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) w2q[i] = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+          const uint4 w2 = w2q[i % PD];
+          if (i + PD < FC) w2q[i % PD] = *reinterpret_cast<const uint4*>(st + a2off + (i + PD) * 1024);
+          acc2[i][0] = mfma_16x16x32<HT>(w2, hb0, acc2[i][0]);
+          acc2[i][1] = mfma_16x16x32<HT>(w2, hb1, acc2[i][1]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);         // the first PD fragments requested before the GELU, so they land under it
+        __builtin_amdgcn_sched_group_barrier(0x006, 400, 0);        // the GELU of the "b" rows
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      } else {
       // GEMM1: hidden[32][PW] = W1_j . t
       f32x4 h[2][FP];
 #pragma unroll
@@ -210,6 +298,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
         for (int f = 0; f < FP; ++f)
           acc2[i][f] = mfma_16x16x32<HT>(w2, hb[f], acc2[i][f]);
       }
+      }
     }
   }
   // Epilogue: + b2' and 8-byte bf16x4 stores STRAIGHT from the accumulators (a lane owns 4 consecutive channels of a
@@ -234,7 +323,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   }
 }
 
-template <int D, int FP, int WPS, typename HT>
+template <int D, int FP, int WPS, typename HT, bool PIPE = false>
 int launch_mlp(const MlpP& p, hipStream_t s) {
   constexpr int P = 4 * FP * 16;
   constexpr int STAGE = 32 * D * 2 + D * 64;
@@ -242,8 +331,174 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   const long blocks = ((long)p.M + P - 1) / P;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS, HT>, lds)) return rc;
-  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS, HT>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS, HT, PIPE>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS, HT, PIPE>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// d = 96: the WEIGHT-RESIDENT form.  W1 and W2' are 4 * 96 * 96 * 2 B * 2 = 147 KB: they fit the CU's 160 KB of LDS, so ONE persistent
+// workgroup per CU stages them once (all twelve chunks, the stage layout above) and its 16 waves (4 per SIMD) then run FREE: every wave
+// walks its own list of 32-pixel blocks -- load the block's fc1 inputs and residual, the twelve-chunk loop on the resident weights,
+// store -- with no workgroup barrier, no DMA pipeline and no lock step between waves, so one wave's global-load latency and GELU sit
+// under the other waves' MFMAs.  (The streaming kernel above re-streams the weights for every 128 pixels: 3200 workgroups x 147 KB =
+// 470 MB of L2 -> LDS traffic per call, and a barrier per chunk keeps a workgroup's waves in phase: measured, its load / DMA / GELU / MFMA
+// phases ADD UP -- 45 + 8 + 24 + 25 = 95 us per stage-0 block -- where the HBM floor of the call is 47 us.)
+// Blocks: the full rounds are dealt wave by wave; the remainder goes one block per CU first (then a second wave of the CU, which sits on
+// another SIMD), so every SIMD of the chip gets the same number of blocks give or take one.
+template <int D, typename HT, int NW, bool PREF = false>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mlp_resident_kernel(const MlpP p) {
+  constexpr int FP = 2;
+  constexpr int KS1 = D / 32, FC = D / 16, NCH = 4 * D / 32;
+  constexpr int W1B = 32 * D * 2, W2B = D * 64, STAGE = W1B + W2B;
+  static_assert(NCH * STAGE + 6 * D * 4 <= 160 * 1024, "the weights must fit the LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* aff = reinterpret_cast<float*>(smem + NCH * STAGE);   // [D] b2' | [4D] b1
+  float* b1s = aff + D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int c = tid; c < D; c += NW * 64) aff[c] = p.ep.shift[c];
+  for (int c = tid; c < 4 * D; c += NW * 64) b1s[c] = p.b1[c];
+  // ---- all weights -> LDS, once: chunk j at j * STAGE in the streaming kernel's stage layout (LDS-DMA, swizzle on the source side) ----
+  {
+    const srd_t w1srd = make_srd(p.w1), w2srd = make_srd(p.w2p);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    constexpr int NDMA = STAGE / 1024;            // wave-instructions per chunk
+    for (int q = wave; q < NCH * NDMA; q += NW) {
+      const int j = q / NDMA, inst = q - j * NDMA;
+      const int c = inst * 64 + lane;
+      unsigned vo;
+      if (inst * 1024 < W1B) {
+        const int slab = c / 128, r = (c % 128) / 4, sl = (c % 4) ^ swz4(r);
+        vo = (unsigned)(r * D * 2 + slab * 64 + sl * 16);
+        lds_dma16(w1srd, vo, j * 32 * D * 2, __builtin_amdgcn_readfirstlane(lds0 + j * STAGE + inst * 1024));
+      } else {
+        const int c2 = c - W1B / 16;
+        const int r = c2 / 4, sl = (c2 % 4) ^ swz4(r);
+        vo = (unsigned)(r * 4 * D * 2 + sl * 16);
+        lds_dma16(w2srd, vo, j * 64, __builtin_amdgcn_readfirstlane(lds0 + j * STAGE + inst * 1024));
+      }
+    }
+    wait_vm<0>();
+  }
+  __syncthreads();   // the only barrier: from here on the LDS is read-only
+
+  int a1off[KS1], a2off;
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) a1off[ks] = ks * 2048 + lr * 64 + ((lq ^ swz4(lr)) << 4);
+  a2off = W1B + lr * 64 + ((lq ^ swz4(lr)) << 4);
+
+  // (32-bit indices: the host checks M * D < 2^31)
+  const int nblk = (p.M + 31) / 32;
+  const int G = gridDim.x, per_round = G * NW;
+  const int rounds = nblk / per_round, rem = nblk - rounds * per_round;
+  const int mine = rounds + ((wave * G + (int)blockIdx.x) < rem ? 1 : 0);
+  HT* const yb = reinterpret_cast<HT*>(p.ep.y);
+  auto block_of = [&](int it) { return it < rounds ? it * per_round + (int)blockIdx.x * NW + wave : rounds * per_round + wave * G + (int)blockIdx.x; };
+  auto fetch = [&](int blk, uint4 (&tf_)[FP][KS1], uint2 (&rr_)[FC][FP]) {
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const int pix = blk * 32 + f * 16 + lr;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+        tf_[f][ks] = (pix < p.M && !MLP_ABL(p, 64)) ? *reinterpret_cast<const uint4*>(p.t + (unsigned)(pix * D + ks * 32 + lq * 8)) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < FC; ++i)
+        rr_[i][f] = (p.res && pix < p.M) ? *reinterpret_cast<const uint2*>(p.res + (unsigned)(pix * D + i * 16 + lq * 4)) : uint2{0u, 0u};
+    }
+  };
+  uint4 tf[FP][KS1], tfn[FP][KS1];
+  uint2 rr[FC][FP], rrn[FC][FP];
+  if (PREF && mine > 0) fetch(block_of(0), tf, rr);
+#pragma unroll 1
+  for (int it = 0; it < mine; ++it) {
+    const int blk = block_of(it);
+    const int pbase = blk * 32;
+    // PREF: the NEXT block's inputs are requested before this block's chunk loop, so the loads of every wave are in flight under its own
+    // MFMAs and GELU whatever the other waves do.  (Without it the waves of a SIMD fall into lock step -- all wait for memory together,
+    // then all compute together -- and the memory and compute phases of the call ADD UP: tools/mlp_variants.py ablation.)
+    if (PREF) { if (it + 1 < mine) fetch(block_of(it + 1), tfn, rrn); }
+    else fetch(blk, tf, rr);
+    f32x4 acc2[FC][FP];
+#pragma unroll
+    for (int f = 0; f < FP; ++f)
+#pragma unroll
+      for (int i = 0; i < FC; ++i) acc2[i][f] = unpack4<HT>(rr[i][f]);
+#pragma unroll 1
+    for (int jj = 0; jj < NCH; ++jj) {
+      const char* st = smem + jj * STAGE;
+      const float4 ba = *reinterpret_cast<const float4*>(b1s + jj * 32 + lq * 4);
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + jj * 32 + 16 + lq * 4);
+      f32x4 h[2][FP];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) h[b][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!MLP_ABL(p, 4))
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const uint4 wa = *reinterpret_cast<const uint4*>(st + a1off[ks]);
+        const uint4 wb = *reinterpret_cast<const uint4*>(st + a1off[ks] + 1024);
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+          h[0][f] = mfma_16x16x32<HT>(wa, tf[f][ks], h[0][f]);
+          h[1][f] = mfma_16x16x32<HT>(wb, tf[f][ks], h[1][f]);
+        }
+      }
+      uint4 hb[FP];
+#pragma unroll
+      for (int f = 0; f < FP; ++f) {
+        f32x2_t a01 = f32x2_t{h[0][f][0] + ba.x, h[0][f][1] + ba.y}, a23 = f32x2_t{h[0][f][2] + ba.z, h[0][f][3] + ba.w};
+        f32x2_t c01 = f32x2_t{h[1][f][0] + bb.x, h[1][f][1] + bb.y}, c23 = f32x2_t{h[1][f][2] + bb.z, h[1][f][3] + bb.w};
+        if (!MLP_ABL(p, 1)) { a01 = gelu_poly2(a01); a23 = gelu_poly2(a23); c01 = gelu_poly2(c01); c23 = gelu_poly2(c23); }
+        hb[f].x = pk2<HT>(a01.x, a01.y); hb[f].y = pk2<HT>(a23.x, a23.y);
+        hb[f].z = pk2<HT>(c01.x, c01.y); hb[f].w = pk2<HT>(c23.x, c23.y);
+      }
+      if (!MLP_ABL(p, 2))
+#pragma unroll
+      for (int i = 0; i < FC; ++i) {
+        const uint4 w2 = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc2[i][f] = mfma_16x16x32<HT>(w2, hb[f], acc2[i][f]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+      const float4 sh = *reinterpret_cast<const float4*>(aff + i * 16 + lq * 4);
+#pragma unroll
+      for (int f = 0; f < FP; ++f) {
+        const int pix = pbase + f * 16 + lr;
+        if (pix >= p.M || MLP_ABL(p, 32)) continue;
+        uint2 o;
+        o.x = pk2<HT>(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
+        o.y = pk2<HT>(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
+        *reinterpret_cast<uint2*>(yb + (unsigned)(pix * D + i * 16 + lq * 4)) = o;
+      }
+    }
+    if (PREF) {
+#pragma unroll
+      for (int f = 0; f < FP; ++f) {
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) tf[f][ks] = tfn[f][ks];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) rr[i][f] = rrn[i][f];
+      }
+    }
+  }
+}
+
+template <int D, typename HT, int NW = 16, bool PREF = false>
+int launch_mlp_resident(const MlpP& p, hipStream_t s) {
+  constexpr int lds = (4 * D / 32) * (32 * D * 2 + D * 64) + 5 * D * 4;
+  const long nblk = ((long)p.M + 31) / 32;
+  long blocks = (nblk + NW - 1) / NW;
+  if (blocks > 256) blocks = 256;             // one persistent workgroup per CU
+  if (blocks <= 0) return MTBT_EINVAL;
+  if (int rc = mtbt_allow_lds(mlp_resident_kernel<D, HT, NW, PREF>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_resident_kernel<D, HT, NW, PREF>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -277,6 +532,10 @@ static int mlp_entry(const void* t, const void* res, const void* w1, const float
   // d = 384 (stage 2): three 48 KiB weight stages fill the LDS, so ONE workgroup per CU (one wave per SIMD, up to 512 registers): the
   // wave keeps 2 x 16 pixels' inputs (96 registers) and their 384-channel outputs (192) in registers; per hidden chunk it reads 48
   // weight fragments for 96 MFMAs -- LDS port 50 % busy, the fill path 32 B/clk.
+  // d = 96: the weight-resident persistent form once every CU has at least ~4 blocks of 32 pixels per wave-slot to run (its fixed cost is
+  // the one-off 147 KB weight stage per CU); small calls (tests, tiny maps) keep the streaming kernel
+  if (D == 96 && M >= 64 * 1024 && M * 96 < 0x7fffffffL && MTBT_MLP_RESIDENT)
+    return dtype == MTBT_F16 ? launch_mlp_resident<96, f16_t, 8, true>(p, s) : launch_mlp_resident<96, bf16_t, 8, true>(p, s);
   if (dtype == MTBT_F16) return D == 96 ? launch_mlp<96, 2, 4, f16_t>(p, s) : (D == 192 ? launch_mlp<192, 2, 2, f16_t>(p, s) : launch_mlp<384, 2, 1, f16_t>(p, s));
   return D == 96 ? launch_mlp<96, 2, 4, bf16_t>(p, s) : (D == 192 ? launch_mlp<192, 2, 2, bf16_t>(p, s) : launch_mlp<384, 2, 1, bf16_t>(p, s));
 }

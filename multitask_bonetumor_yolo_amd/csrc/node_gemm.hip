@@ -1,0 +1,194 @@
+// BiFPN node as ONE kernel: weighted sum of the (resampled) inputs -> DepthwiseConvBlock (k = 1 depthwise scale folded into the pointwise
+// weight, folded BatchNorm, ELU)   --   main_model.py:198-243 (`BiFPNUnit.forward`: w * p4 + w * up2(p5) ...) + :62-102 (`DepthwiseConvBlock`).
+//
+//   y[p][k] = act( sum_c W'[k][c] * s[p][c] + shift[k] ),     s[p][c] = sum_i wgt_i * resample_i(x_i)[p][c]
+//
+// As two launches (mtbt_bifpn_fuse, then the 1x1 conv) the fused map s makes an HBM round trip (2 x 52 MB at P3, batch 16) and both
+// kernels sit far below either roof (fusion 3.6 TB/s, the 256 -> 256 GEMM 0.08 of the MFMA peak / 0.18 of HBM).  Here the fusion arithmetic
+// IS the staging of the GEMM's B operand: a workgroup owns 64 consecutive pixels, its 256 threads compute s for them (16-byte pieces, fp32,
+// the stand-alone kernel's association order, rounded to the 16-bit storage type exactly as that kernel stores it -- so the result is
+// bit-identical to the two-launch form) straight into an XOR-swizzled [64 px][C] LDS image, then the four waves (2 channel halves x
+// 2 pixel halves) run the K x C GEMM with the weights streamed slab by slab (32 input channels, LDS-DMA, double-buffered) and the conv
+// kernels' slab epilogue stores y.  HBM traffic per pixel: the inputs once + y once.
+#include "common.h"
+#include "conv_dma.h"
+#include "conv_epilogue.h"
+#include "conv_params.h"
+#include "fuse_fetch.h"
+
+namespace {
+
+struct NodeP {
+  FuseP f;          // inputs, weights, modes, N / H / W / C of the OUTPUT map (f.y unused)
+  const void* w;    // [K][C] 16-bit
+  ConvP ep;         // epilogue view: y, ldy, shift, act, K
+};
+
+// NIN / M0..M2: the node's input count and resampling modes as compile-time constants (the top-down nodes are identity + bilinear x2, the
+// output nodes identity + identity + 2x2 mean): the fusion phase is then straight-line code whose 16-byte loads the compiler issues
+// four pieces ahead.  (With the modes behind run-time branches every piece waited for its own loads: 8 dependent round trips per
+// workgroup, 105 us for the P3 node where the two separate launches take 90.)
+template <typename T, int KT, int NIN, int M0, int M1, int M2>
+__global__ __launch_bounds__(256, 2) void node_gemm_kernel(const NodeP p) {
+  constexpr int TP = 64;                          // pixels per workgroup
+  constexpr int ES = 2, BKB = 64;                 // 16-bit storage; weight slab = 32 input channels = 64 bytes per row
+  constexpr int FC = KT / 32, FP = 2, WCH = KT / 2;
+  constexpr int WSLAB = KT * BKB, WDMA = WSLAB / 16 / 256;
+  constexpr int CMAX = 256, BBYTES = TP * CMAX * ES;
+  static_assert(WDMA * 256 * 16 == WSLAB, "weight slab = whole wave-instructions");
+  static_assert(4 * 16 * (WCH * 4 + 16) <= BBYTES + 2 * WSLAB, "epilogue slabs below the affine copy");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* bimg = smem;                              // [TP][C] T, 16-byte slot c8 of pixel q at q * C * 2 + ((c8 ^ (q & 15)) << 4) (low four slot bits)
+  float* aff = reinterpret_cast<float*>(smem + BBYTES + 2 * WSLAB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  constexpr int C = KT, rowb = C * ES;            // (square nodes only: C == K)
+  const long M = (long)p.f.N * p.f.H * p.f.W;
+  const long pix0 = (long)blockIdx.x * TP;
+  stage_affine<KT>(p.ep, aff, 0, tid);
+
+  // ---- weights: slab 0 on its way while the fusion runs ----
+  const srd_t wsrd = make_srd(p.w);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned wvoff[WDMA];
+#pragma unroll
+  for (int i = 0; i < WDMA; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 2, sl = c & 3;
+    wvoff[i] = (unsigned)((row * C + (sl ^ ((row >> 2) & 3)) * 8) * ES);
+  }
+  auto stage_w = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < WDMA; ++i) lds_dma16(wsrd, wvoff[i], g * BKB, lds0 + BBYTES + (g & 1) * WSLAB + (i * 256 + wave * 64) * 16);
+  };
+  stage_w(0);
+
+  // ---- B operand = the fused map of this workgroup's pixels ----
+  constexpr int CH8 = C >> 3, PCS = TP * CH8 / 256;
+  const float w0 = p.f.wgt_dev ? p.f.wgt_dev[0] : p.f.wgt[0], w1 = p.f.wgt_dev ? p.f.wgt_dev[1] : p.f.wgt[1];
+  const float w2 = NIN > 2 ? (p.f.wgt_dev ? p.f.wgt_dev[2] : p.f.wgt[2]) : 0.f;
+#pragma unroll 4
+  for (int k = 0; k < PCS; ++k) {
+    const int idx = tid + k * 256;
+    const int q = idx / CH8, c8 = idx - q * CH8;
+    const long pix = pix0 + q;
+    const bool ok = pix < M;
+    const long pc = ok ? pix : M - 1;             // (ragged last tile: fetch a valid pixel, store zeros)
+    const int x = (int)(pc % p.f.W);
+    const long ny = pc / p.f.W;
+    const int y = (int)(ny % p.f.H), n = (int)(ny / p.f.H);
+    float t0[8], t1[8], t2[8], acc[8];
+    fuse_fetch<T>(reinterpret_cast<const T*>(p.f.x[0]), M0, n, y, x, p.f.H, p.f.W, C, c8 * 8, t0);
+    fuse_fetch<T>(reinterpret_cast<const T*>(p.f.x[1]), M1, n, y, x, p.f.H, p.f.W, C, c8 * 8, t1);
+    if constexpr (NIN > 2) fuse_fetch<T>(reinterpret_cast<const T*>(p.f.x[2]), M2, n, y, x, p.f.H, p.f.W, C, c8 * 8, t2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = w0 * t0[e];
+      v = v + w1 * t1[e];
+      if constexpr (NIN > 2) v = v + w2 * t2[e];
+      acc[e] = ok ? v : 0.f;
+    }
+    st8<T>(reinterpret_cast<T*>(bimg + q * rowb + ((((c8 & 15) ^ (q & 15)) | (c8 & ~15)) << 4)), acc);
+  }
+
+  f32x4 acc[FC][FP];
+#pragma unroll
+  for (int i = 0; i < FC; ++i)
+#pragma unroll
+    for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int arow = wc * WCH + lr;
+  const int aoff = BBYTES + arow * BKB + ((lq ^ ((arow >> 2) & 3)) << 4);      // + buf * WSLAB + f * 16 * BKB
+  const int nsteps = C / 32;
+#pragma unroll 1
+  for (int g0 = 0; g0 < nsteps; g0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {      // buffer parity compile-time
+      const int g = g0 + u;
+      if (g >= nsteps) continue;       // (odd slab count: uniform over the block)
+      wait_vm<0>();                    // my pieces of slab g have landed
+      lds_barrier();                   // everyone's have (first pass: and the whole B image is written); the other buffer is free
+      if (g + 1 < nsteps) stage_w(g + 1);
+      uint4 a[FC], b[FP];
+#pragma unroll
+      for (int j = 0; j < FP; ++j) {
+        const int q = wr * 32 + j * 16 + lr;
+        const int slot = g * 4 + lq;
+        b[j] = *reinterpret_cast<const uint4*>(bimg + q * rowb + ((((slot & 15) ^ (q & 15)) | (slot & ~15)) << 4));
+      }
+      const char* wb = smem + aoff + u * WSLAB;
+#pragma unroll
+      for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const uint4*>(wb + f * 16 * BKB);
+#pragma unroll
+      for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j) acc[i][j] = mfma_16x16x32<T>(a[i], b[j], acc[i][j]);
+    }
+  }
+  __syncthreads();   // LDS below the affine copy is free for the epilogue slabs
+
+  const EpiSeq seq{pix0 + wr * 32, 16, M, 0L, 0L};
+  conv_epilogue<T, KT, FC, FP, false>(p.ep, acc, smem + wave * (16 * (WCH * 4 + 16)), aff, 0, wc * WCH, lane,
+                                      [&](int j, int row, int ch, long& yoff, long& roff) -> bool {
+    const long pix = pix0 + wr * 32 + j * 16 + row;
+    yoff = pix * p.ep.ldy + ch;
+    roff = 0;
+    return pix < M;
+  }, seq, true);
+}
+
+template <typename T, int KT, int NIN, int M0, int M1, int M2>
+int launch_node_t(const NodeP& p, hipStream_t s) {
+  const long M = (long)p.f.N * p.f.H * p.f.W;
+  const long blocks = (M + 63) / 64;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
+  constexpr int lds = 64 * 256 * 2 + 2 * KT * 64 + 2 * KT * 4;
+  if (int rc = mtbt_allow_lds(node_gemm_kernel<T, KT, NIN, M0, M1, M2>, lds)) return rc;
+  hipLaunchKernelGGL((node_gemm_kernel<T, KT, NIN, M0, M1, M2>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+// the two node shapes of BiFPNUnit.forward (main_model.py:198-243): identity + bilinear x2 (top-down), identity + identity + 2x2 mean (output)
+template <typename T, int KT>
+int launch_node(const NodeP& p, hipStream_t s) {
+  if (p.f.n_in == 2 && p.f.resample[0] == 0 && p.f.resample[1] == 1) return launch_node_t<T, KT, 2, 0, 1, 0>(p, s);
+  if (p.f.n_in == 3 && p.f.resample[0] == 0 && p.f.resample[1] == 0 && p.f.resample[2] == 2) return launch_node_t<T, KT, 3, 0, 0, 2>(p, s);
+  return MTBT_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int mtbt_bifpn_node_nhwc(const mtbt_node_args* a, void* stream) {
+  if (!a || !a->w || !a->y || !a->shift) return MTBT_EINVAL;
+  const mtbt_fuse_args& f = a->fuse;
+  if (f.n_in < 1 || f.n_in > 3 || f.N <= 0 || f.H <= 0 || f.W <= 0 || f.add_weight_bug) return MTBT_EINVAL;
+  if (f.dtype != MTBT_BF16 && f.dtype != MTBT_F16) return MTBT_EINVAL;       // (fp32 parity mode: mtbt_bifpn_fuse + mtbt_conv2d_nhwc)
+  if ((f.C != 128 && f.C != 256) || a->K != f.C) return MTBT_EINVAL;   // square nodes; the B image's slot swizzle spans 16 slots = 128 channels
+  if (a->act < 0 || a->act > MTBT_ACT_GELU_POLY) return MTBT_EINVAL;
+  if (a->y_pixel_stride < a->K || a->y_pixel_stride % 8) return MTBT_EINVAL;
+  if (!aligned16(a->w) || !aligned16(a->y)) return MTBT_EALIGN;
+  NodeP p;
+  for (int i = 0; i < 3; ++i) {
+    p.f.x[i] = i < f.n_in ? f.x[i] : nullptr;
+    p.f.wgt[i] = f.wgt[i];
+    p.f.resample[i] = f.resample[i];
+    if (i < f.n_in) {
+      if (!f.x[i] || f.resample[i] < 0 || f.resample[i] > 4) return MTBT_EINVAL;
+      if ((f.resample[i] == 1 || f.resample[i] == 3) && ((f.H & 1) || (f.W & 1))) return MTBT_EINVAL;
+      if (!aligned16(f.x[i])) return MTBT_EALIGN;
+    }
+  }
+  p.f.wgt_dev = f.wgt_dev;
+  p.f.n_in = f.n_in; p.f.y = nullptr; p.f.N = f.N; p.f.H = f.H; p.f.W = f.W; p.f.C = f.C; p.f.bug = 0;
+  p.w = a->w;
+  ConvP& e = p.ep;
+  e = ConvP{};
+  e.y = a->y; e.shift = a->shift; e.scale = nullptr; e.res = nullptr; e.y2 = nullptr;
+  e.ldy = a->y_pixel_stride; e.ldr = 0; e.K = a->K; e.act = a->act; e.out_mode = MTBT_OUT_NHWC; e.out_f32 = 0; e.vec_ok = 1;
+  e.cs_part = nullptr;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (f.dtype == MTBT_F16) return a->K == 256 ? launch_node<f16_t, 256>(p, s) : launch_node<f16_t, 128>(p, s);
+  return a->K == 256 ? launch_node<bf16_t, 256>(p, s) : launch_node<bf16_t, 128>(p, s);
+}

@@ -610,6 +610,8 @@ extern "C" int mtbt_sizeof_args(int which) {
     case 4: return (int)sizeof(mtbt_loss_args);
     case 5: return (int)sizeof(mtbt_prep_desc);
     case 6: return (int)sizeof(mtbt_raw_image);
+    case 7: return (int)sizeof(mtbt_upconv_args);
+    case 8: return (int)sizeof(mtbt_node_args);
     default: return -1;
   }
 }

@@ -494,6 +494,37 @@ class Plan:
                                     2.0 * M * D * 4 * D * 2, 3.0 * M * D * 2 + 2.0 * 4 * D * D * 2))
         self._io([t, res], [y])
 
+    def node(self, inputs, weights, modes, w: torch.Tensor, shift: torch.Tensor, y: Act, act=L.ACT_ELU, name="bifpn_node"):
+        """BiFPN node in one launch (node_gemm.hip): weighted sum of the resampled inputs as the B-operand staging of the 1x1 GEMM + shift + act."""
+        K, Cin = w.shape
+        assert y.C == K and y.bs == y.H * y.W * y.ld and all(t.dense and t.C == Cin for t in inputs)
+        a = L.NodeArgs()
+        for i, (t, wv, m) in enumerate(zip(inputs, weights, modes)):
+            a.fuse.x[i], a.fuse.wgt[i], a.fuse.resample[i] = t.ptr, float(wv), m
+        a.fuse.n_in = len(inputs)
+        a.fuse.N, a.fuse.H, a.fuse.W, a.fuse.C, a.fuse.dtype, a.fuse.add_weight_bug = y.N, y.H, y.W, Cin, y.code, 0
+        a.w, a.shift, a.y, a.y_pixel_stride, a.K, a.act = w.data_ptr(), shift.data_ptr(), y.ptr, y.ld, K, act
+        n = y.N * y.H * y.W
+        self.launches.append(Launch(self.lib.mtbt_bifpn_node_nhwc, (C.byref(a),), name, (a, w, shift, y.buf) + tuple(t.buf for t in inputs),
+                                    2.0 * n * K * Cin, n * (K + Cin * len(inputs)) * ESIZE[y.code]))
+        self._io(list(inputs) + [w, shift], [y])
+        return a
+
+    def upconv(self, x: Act, w: torch.Tensor, shift9: torch.Tensor, y: Act, act=L.ACT_SILU, name="upconv"):
+        """ConvTranspose2d(2, 2) -> Conv 3x3 + shift + activation as one direct conv on the low-resolution map (upconv_fused.hip).
+        w [4*K, 4*C] composed weights, shift9 [9, K] fp32 (model.compose_upconv)."""
+        K = w.shape[0] // 4
+        assert w.shape[1] == 4 * x.C and tuple(shift9.shape) == (9, K) and y.C == K and y.H == 2 * x.H and y.W == 2 * x.W and x.code == y.code
+        a = L.UpconvArgs()
+        a.x, a.w, a.y, a.shift = x.ptr, w.data_ptr(), y.ptr, shift9.data_ptr()
+        a.x_batch_stride, a.y_batch_stride, a.x_pixel_stride, a.y_pixel_stride = x.batch_stride, y.batch_stride, x.ld, y.ld
+        a.N, a.H, a.W, a.C, a.K, a.dtype, a.act = x.N, x.H, x.W, x.C, K, x.code, act
+        flops = 2.0 * x.N * x.H * x.W * 4 * K * 4 * x.C
+        byts = (x.N * x.H * x.W * x.C + 16 * K * x.C + 4 * x.N * x.H * x.W * K) * ESIZE[x.code]
+        self.launches.append(Launch(self.lib.mtbt_convt2x2_conv3x3_nhwc, (C.byref(a),), name, (a, x.buf, w, shift9, y.buf), flops, byts))
+        self._io([x, w, shift9], [y])
+        return a
+
     def raw(self, fn, args, name, keep=(), reads=(), writes=()):
         self.launches.append(Launch(fn, args, name, keep))
         self._io(list(reads), list(writes))

@@ -222,6 +222,29 @@ def _krsc(w: torch.Tensor) -> torch.Tensor:
     return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
 
 
+def compose_upconv(wt: torch.Tensor, bt: torch.Tensor, w3: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor):
+    """ConvTranspose2d(Ci, Cm, 2, 2, bias bt) followed by Conv2d(Cm, K, 3, pad 1, no bias) * scale + shift (a folded BatchNorm), composed
+    for `mtbt_convt2x2_conv3x3_nhwc` (include/mtbt_hip.h): both operators are linear, so per output parity (a, b) the nine taps collapse
+    onto 2 x 2 source pixels.  wt [Ci, Cm, 2, 2], w3 [K, Cm, 3, 3]  ->  (w [4K, 4Ci] = [q][k][rho][sigma][ci], shift9 [9, K]), all fp32.
+    Upsampled row 2i + a + dy is source row i + floor((a + dy) / 2), sub-row (a + dy) mod 2; rho = floor((a + dy) / 2) - (a - 1)."""
+    wt, bt, w3 = wt.detach().double(), bt.detach().double(), w3.detach().double() * scale.detach().double()[:, None, None, None]
+    K, Ci = w3.shape[0], wt.shape[0]
+    w = torch.zeros(2, 2, K, 2, 2, Ci, dtype=torch.float64, device=w3.device)
+    for a in range(2):
+        for b in range(2):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    rho, sy = (a + dy) // 2 - (a - 1), (a + dy) % 2
+                    sig, sx = (b + dx) // 2 - (b - 1), (b + dx) % 2
+                    w[a, b, :, rho, sig, :] += w3[:, :, dy + 1, dx + 1] @ wt[:, :, sy, sx].t()
+    # bias of the transposed conv through the taps that lie inside the upsampled map: class 0 = first output row (the dy = -1 taps fall
+    # into the zero padding), 2 = last row (dy = +1 missing), 1 = interior; the same for columns
+    tapb = torch.einsum("kcyx,c->kyx", w3, bt)                                  # [K, 3, 3]
+    valid = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}
+    shift9 = torch.stack([shift.detach().double() + tapb[:, list(valid[rc])][:, :, list(valid[cc])].sum(dim=(1, 2)) for rc in range(3) for cc in range(3)])
+    return w.reshape(4 * K, 4 * Ci).float(), shift9.float()
+
+
 class _Lowering:
     """Builds the launch plan for one (batch, size, dtype, mode) from the module tree."""
 
@@ -465,10 +488,22 @@ class _Lowering:
             a, b = self._norm_w(u.w1, u.eps), self._norm_w(u.w2, u.eps)
 
             def node(inputs, weights, modes, like: Act, conv, cf, tag):
-                s = self.p.new(like.N, like.H, like.W, like.C, self.code)
-                self.p.fuse(inputs, [float(v) for v in weights], modes, s, name=f"{nm}.{tag}.fuse")
-                d = self.dw_pointwise(s, conv, f"{nm}.{tag}_conv")
-                self.p.release(s)
+                K = conv.pointwise.out_channels
+                shapes = ([L.RES_ID, L.RES_UP_BILINEAR], [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN])
+                if (self.code in (L.BF16, L.F16) and like.C in (128, 256) and K == like.C and list(modes) in shapes and not conv.bn.training
+                        and os.environ.get("MTBT_NODE_FUSED", "1") == "1"):
+                    # weighted sum + resample + DepthwiseConvBlock (scale folded, BN folded, ELU) in ONE launch: the fused map never reaches HBM
+                    dw = conv.depthwise.weight.detach().float().reshape(1, -1)
+                    pw = conv.pointwise.weight.detach().float().reshape(K, -1) * dw
+                    scale, shift = _bn_fold(conv.bn)
+                    d = self.p.new(like.N, like.H, like.W, K, self.code)
+                    self.p.node(inputs, [float(v) for v in weights], modes, self.W(pw * scale[:, None]), self.F(shift), d, act=L.ACT_ELU,
+                                name=f"{nm}.{tag}.fuse+conv")
+                else:
+                    s = self.p.new(like.N, like.H, like.W, like.C, self.code)
+                    self.p.fuse(inputs, [float(v) for v in weights], modes, s, name=f"{nm}.{tag}.fuse")
+                    d = self.dw_pointwise(s, conv, f"{nm}.{tag}_conv")
+                    self.p.release(s)
                 o = self.c2f(d, cf, f"{nm}.{tag}_cf")
                 self.p.release(d)
                 return o
@@ -493,7 +528,11 @@ class _Lowering:
         (the `torch.cat((cv2_i, cv3_i), 1)` of Detect.forward without the copy)."""
         maps = []
         for i, f in enumerate(feats):
-            full = self.f32_out(f.N, f.H, f.W, head.no)
+            # pixel pitch rounded up to 4 floats (66 -> 68): the 64-channel box slice then starts every pixel on a 16-byte boundary and the
+            # conv epilogue stores it with 16-byte accesses (at pitch 66 it fell back to 64 scalar stores per pixel: 43 us per P3 map, 0.11 of HBM)
+            ld = (head.no + 3) // 4 * 4
+            buf = torch.empty((f.N, f.H, f.W, ld), dtype=torch.float32, device=self.x.device)
+            full = Act(buf, 0, f.N, f.H, f.W, head.no, ld, f.H * f.W * ld)
             s = head.cv2[i]
             t1 = self.convblock(f, s[0], None, f"{tag}.cv2.{i}.0")
             t2 = self.convblock(t1, s[1], None, f"{tag}.cv2.{i}.1")
@@ -530,6 +569,19 @@ class _Lowering:
             off += f.H * f.W
         pr, f = head.proto, feats[0]
         t1 = self.convblock(f, pr.cv1, None, "segment.proto.cv1")
+        if (not pr.cv2.bn.training and f.H % 16 == 0 and f.W % 16 == 0 and pr.cv2.conv.out_channels % 128 == 0
+                and os.environ.get("MTBT_PROTO_FUSED", "1") == "1"):
+            # upsample (ConvTranspose 2x2 / 2 + bias) and cv2 (3x3 + BN + SiLU) are linear with nothing in between: ONE 2x2-tap direct conv
+            # per output parity on the low-resolution map -- 4/10 of the MACs, no [N, 2H, 2W, 256] tensor written and read back
+            sc, sh = _bn_fold(pr.cv2.bn)
+            wc, shift9 = compose_upconv(pr.upsample.weight, pr.upsample.bias, pr.cv2.conv.weight, sc, sh)
+            t2 = self.p.new(f.N, 2 * f.H, 2 * f.W, pr.cv2.conv.out_channels, self.code)
+            self.p.upconv(t1, self.W(wc), self.F(shift9), t2, act=L.ACT_SILU, name="segment.proto.upsample+cv2")
+            self.p.release(t1)
+            protos = self.f32_out(f.N, 2 * f.H, 2 * f.W, head.nm)
+            self.convblock(t2, pr.cv3, protos, "segment.proto.cv3")
+            self.p.release(t2)
+            return mc, protos
         up = self.p.new(f.N, 2 * f.H, 2 * f.W, pr.upsample.out_channels, self.code)
         wt = pr.upsample.weight.detach()  # [Cin, Cout, 2, 2] -> GEMM rows (dy*2+dx)*Cout + co
         self.p.conv(t1, self.W(wt.permute(2, 3, 1, 0).reshape(4 * wt.shape[1], wt.shape[0])), up,
@@ -934,20 +986,57 @@ def init_synthetic_(model: nn.Module, seed: int = 0) -> nn.Module:
     return model
 
 
+def synthetic_images(B: int, S: int, seed: int = 0) -> torch.Tensor:
+    """Synthetic input batch [B,3,S,S] in [0,1): uniform noise carrying a few large soft blobs per image (2-5, sigma S/20 .. S/8, a
+    colour each).  Pure noise makes every position of every feature map statistically the same, so no head -- trained or calibrated -- has
+    anything to localise and the kept-box set is a coin toss per anchor; the blobs give the pyramid a handful of "objects" (the reference's
+    radiographs: one lesion on a bone, `dataset_btxrdv2.py`), the noise keeps every operand bit toggling (no DVFS bonus from smooth data)."""
+    g = torch.Generator().manual_seed(10_000 + seed)
+    x = torch.rand(B, 3, S, S, generator=g) * 0.5
+    yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float32), torch.arange(S, dtype=torch.float32), indexing="ij")
+    for b in range(B):
+        for _ in range(int(torch.randint(2, 6, (1,), generator=g))):
+            cy, cx = (torch.rand(2, generator=g) * 0.7 + 0.15).tolist()
+            sg = float(torch.rand(1, generator=g)) * (S / 8 - S / 20) + S / 20
+            amp = torch.rand(3, generator=g) * 0.5
+            blob = torch.exp(-((yy - cy * S) ** 2 + (xx - cx * S) ** 2) / (2 * sg * sg))
+            x[b] += amp[:, None, None] * blob[None]
+    return x.clamp_(0.0, 0.999)
+
+
 @torch.no_grad()
-def calibrate_synthetic_heads_(model: nn.Module, x: torch.Tensor, cand_frac=(0.02, 0.30, 0.90), logit_std: float = 2.0, conf_th: float = 0.05,
-                               box_bins: float = 11.0, box_gain: float = 4.0) -> nn.Module:
+def calibrate_synthetic_heads_(model: nn.Module, x: torch.Tensor, cand_frac: float = 0.12, conf_th: float = 0.05, top_score: float = 0.95,
+                               box_bins: float = 11.0, box_gain: float = 4.0, top_quantile: float = 0.999) -> nn.Module:
     """Make the random-initialised Detect / Segment heads behave like trained ones on the synthetic batch `x` ("8400 boxes per
     image ... so that about 10^3 pass conf 0.05").  Untouched, every class score of a random head is sigmoid(~0) = 0.5: all 8400 anchors
     are candidates, top-100 is decided below any arithmetic's resolution and the NMS input is degenerate (round 2's VERDICT, weak #2).
-    One forward on the device measures the class-logit mean / spread per pyramid level; the last class conv of every level (`cv3[i][2]`,
-    main_model.py:324 [ultralytics Detect]) is then rescaled and re-biased so that its logits have standard deviation `logit_std` and the
-    fraction `cand_frac[i]` of the level's anchors passes `conf_th` (640^2: ~130 + ~480 + ~360 candidates per image, scores spread
-    over (0.01, 0.99)); the box conv (`cv2[i][2]`) gets a gain and a bias ramp over the DFL bins so that the expected side is ~`box_bins`
-    bins with per-anchor variation.  Deterministic for a given seed / input; changes parameters in place (plans re-lower by themselves)."""
+    One forward on the device measures, per pyramid level, the distribution of the best-class logit over the anchors; the last class conv
+    of the level (`cv3[i][2]`, main_model.py:324 [ultralytics Detect]) is rescaled and re-biased (one gain, one offset: a two-point fit)
+    so that the (1 - cand_frac) quantile lands on logit(conf_th) and the 99.9 % quantile on logit(top_score): ~`cand_frac` of the anchors
+    pass the confidence filter with scores spread over (conf_th, ~top_score).  The box conv (`cv2[i][2]`) gets a gain and a bias ramp
+    over the DFL bins so that the expected side is ~`box_bins` bins with per-anchor variation.  Deterministic for a given seed / input;
+    changes parameters in place (plans re-lower by themselves)."""
     heads = [(h, key) for h, key in ((getattr(model, "detect", None), "detect_features"), (model.segment, None)) if h is not None]
+    # (1) BatchNorm running statistics := the batch statistics of `x` (one train-mode forward with momentum 1): every BatchNorm then really
+    # normalises its input, as in a trained network.  With arbitrary running statistics a deep random network forgets its input -- every
+    # layer adds a constant component, after ~100 layers the head maps are the same for every image and vary only with the distance to the
+    # zero-padded border -- and whatever is calibrated on top of that amplifies rounding noise instead of signal.
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    saved = [(m.momentum, m.training) for m in bns]
+    flags = [(m, m.training) for m in model.modules()]
+    try:
+        for m in bns:
+            m.momentum = 1.0
+        model.train()
+        model(x, "train")
+    finally:
+        for m, (mom, _) in zip(bns, saved):
+            m.momentum = mom
+        for m, tr in flags:
+            m.training = tr
+    model.__dict__.pop("_train_plans", None)            # the calibration batch's training plan (kept activations) is not needed again
     out = model(x, "infer")
-    nd = torch.distributions.Normal(0.0, 1.0)
+    lg = lambda pr: math.log(pr / (1 - pr))
     for head, key in heads:
         feats = out[key] if key is not None else out["segment_protos"][0]
         nb = 4 * head.reg_max
@@ -958,12 +1047,13 @@ def calibrate_synthetic_heads_(model: nn.Module, x: torch.Tensor, cand_frac=(0.0
             e = float((torch.softmax(a * ks, 0) * ks).sum())
             lo, hi = (a, hi) if e < box_bins else (lo, a)
         for i, f in enumerate(feats):
-            logits = f[:, nb:].float()
-            mu, sd = float(logits.mean()), float(logits.std())
+            best = f[:, nb:].float().amax(dim=1).flatten()
+            q = torch.quantile(best[:: max(1, best.numel() // 200_000)], torch.tensor([1.0 - cand_frac, top_quantile], device=best.device))
+            q_lo, q_hi = float(q[0]), float(q[1])
+            g = (lg(top_score) - lg(conf_th)) / max(q_hi - q_lo, 1e-9)
+            c = lg(conf_th) - g * q_lo
             cls = head.cv3[i][2]
-            g = logit_std / max(sd, 1e-6)
-            b0 = math.log(conf_th / (1 - conf_th)) - logit_std * float(nd.icdf(torch.tensor(1.0 - cand_frac[min(i, len(cand_frac) - 1)])))
-            cls.bias.copy_((cls.bias - mu) * g + b0)
+            cls.bias.copy_(cls.bias * g + c)
             cls.weight.mul_(g)
             box = head.cv2[i][2]
             box.weight.mul_(box_gain)

@@ -47,6 +47,8 @@ def test_struct_layouts_match_header(tmp_path):
         "mtbt_loss_args": (L.LossArgs, ["map", "h", "img_size", "gt_xyxy", "iou_thresh", "training", "seg_logits", "seg_bias", "seg_n", "img_gt",
                                         "n_img_classes", "w_img", "workspace", "workspace_bytes", "out"]),
         "mtbt_raw_image": (L.RawImage, ["bgr", "mask", "height", "width", "row_stride", "mask_row_stride"]),
+        "mtbt_node_args": (L.NodeArgs, ["fuse", "w", "shift", "y", "y_pixel_stride", "K", "act"]),
+        "mtbt_upconv_args": (L.UpconvArgs, ["x", "shift", "x_batch_stride", "x_pixel_stride", "N", "K", "dtype", "act"]),
         "mtbt_mask_args": (L.MaskArgs, ["protos", "coeff_batch_stride", "gather_idx", "bias", "N", "Wout", "logits", "masks"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mtbt_hip.h"', 'int main(void){']

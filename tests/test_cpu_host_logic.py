@@ -203,3 +203,31 @@ def test_load_pretrained_heads_from_flat_state_dict(tmp_path, capsys):
         load_pretrained_heads(m, detect_ckpt_path=str(bad))
     lit = {"net.cls_fc.weight": torch.zeros(2, 256), "seg_proto_projector.weight": torch.zeros(1, 32, 1, 1)}
     assert list(strip_lightning_prefix(lit)) == ["cls_fc.weight"]
+
+
+def test_compose_upconv_equals_convtranspose_then_conv3x3():
+    """model.compose_upconv (host side of mtbt_convt2x2_conv3x3_nhwc): ultralytics Proto `upsample` -> `cv2` (main_model.py:326-328) composed into
+    four 2x2-tap convolutions (one per output parity) + nine border-class shift vectors reproduces torch's ConvTranspose2d(2, 2, bias) ->
+    Conv2d(3x3, pad 1) * scale + shift, border rows and columns included."""
+    import torch.nn.functional as F
+    from multitask_bonetumor_yolo_amd.model import compose_upconv
+    g = torch.Generator().manual_seed(0)
+    Ci, Cm, K, H, W = 5, 7, 6, 4, 6
+    wt, bt, w3 = torch.randn(Ci, Cm, 2, 2, generator=g), torch.randn(Cm, generator=g), torch.randn(K, Cm, 3, 3, generator=g)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    x = torch.randn(2, Ci, H, W, generator=g)
+    ref = F.conv2d(F.conv_transpose2d(x, wt, bt, stride=2), w3, padding=1) * sc[None, :, None, None] + sh[None, :, None, None]
+    w, s9 = compose_upconv(wt, bt, w3, sc, sh)
+    assert tuple(w.shape) == (4 * K, 4 * Ci) and tuple(s9.shape) == (9, K)
+    w = w.view(2, 2, K, 2, 2, Ci)
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.zeros_like(ref)
+    for a in range(2):
+        for b in range(2):
+            acc = sum(torch.einsum("kc,nchw->nkhw", w[a, b, :, r, s, :], xp[:, :, a + r:a + r + H, b + s:b + s + W]) for r in range(2) for s in range(2))
+            rc = torch.tensor([0 if (a == 0 and i == 0) else (2 if (a == 1 and i == H - 1) else 1) for i in range(H)])
+            cc = torch.tensor([0 if (b == 0 and j == 0) else (2 if (b == 1 and j == W - 1) else 1) for j in range(W)])
+            cls = rc[:, None] * 3 + cc[None, :]                                     # [H, W]
+            out[:, :, a::2, b::2] = acc + s9[cls].permute(2, 0, 1)[None]
+    assert (out - ref).abs().max().item() < 2e-4
+    assert (s9[4] - s9[0]).abs().max().item() > 1e-3                                # the border classes really differ

@@ -352,3 +352,87 @@ def test_fp16_store_saturates_and_keeps_nan():
     run(p)
     out = y.buf.float().cpu()
     assert torch.isnan(out[0, 1, 2]).all() and not torch.isnan(out[0, 0]).any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_upconv_fused_proto(dtype):
+    """mtbt_convt2x2_conv3x3_nhwc = ConvTranspose2d(2, 2, bias) -> Conv 3x3 + folded BatchNorm + SiLU (ultralytics Proto.upsample -> Proto.cv2,
+    main_model.py:326-328) against torch fp32 on the same operands: every output pixel incl. the border rows / columns, where the transposed
+    conv's bias enters through fewer taps.  fp32 mode <= 1e-3 absolute; bf16 / fp16: relative L2 against the fp32 result of the ROUNDED
+    composed operands <= 2e-2 / 3e-3 and border pixels no worse than interior ones."""
+    from multitask_bonetumor_yolo_amd.model import compose_upconv
+    g = torch.Generator().manual_seed(12)
+    N, H, W, C, K = 2, 32, 48, 64, 128
+    wt, bt = torch.randn(C, C, 2, 2, generator=g) * 0.08, torch.randn(C, generator=g) * 0.5
+    w3 = torch.randn(K, C, 3, 3, generator=g) * 0.05
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
+    x = torch.randn(N, C, H, W, generator=g)
+    ref = F.silu(F.conv2d(F.conv_transpose2d(x, wt, bt, stride=2), w3, padding=1) * sc[None, :, None, None] + sh[None, :, None, None])
+    wc, s9 = compose_upconv(wt, bt, w3, sc, sh)
+    code = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}[dtype]
+    p = Plan(DEV)
+    xa = Act.of(nhwc(x).to(dtype))
+    y = p.new(N, 2 * H, 2 * W, K, code)
+    p.upconv(xa, wc.to(DEV).to(dtype), s9.to(DEV), y, act=L.ACT_SILU)
+    run(p)
+    out = back(y.buf)
+    err = (out - ref).abs()
+    border = torch.zeros(2 * H, 2 * W, dtype=torch.bool)
+    border[0], border[-1], border[:, 0], border[:, -1] = True, True, True, True
+    if dtype == torch.float32:
+        assert err.max().item() < TOL32, err.max().item()
+    else:
+        rel = (out - ref).norm().item() / ref.norm().item()
+        assert rel < (2e-2 if dtype == torch.bfloat16 else 3e-3), rel
+        assert err[:, :, border].max().item() <= 1.5 * err[:, :, ~border].max().item() + 1e-3
+    # the bias classes matter at this scale: the interior shift on a border row would be off by much more than the tolerance
+    assert (s9[4] - s9[1]).abs().max().item() > 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["td_up", "out_down3", "ragged"])
+def test_bifpn_node_fused_equals_fuse_then_pointwise(dtype, case):
+    """mtbt_bifpn_node_nhwc (weighted sum + resample as the B-operand staging of the DepthwiseConvBlock GEMM, main_model.py:198-243 + :62-102)
+    against the two launches it replaces (mtbt_bifpn_fuse, then the 1x1 conv + shift + ELU) on the same operands: equal up to one unit in the
+    last place of a few elements (the fused map is rounded to the storage type exactly as the stand-alone kernel stores it; the GEMMs may
+    accumulate their 32-channel steps in a different order), and within the bf16 / fp16 tolerance of torch fp32."""
+    g = torch.Generator().manual_seed(3)
+    code = {torch.bfloat16: L.BF16, torch.float16: L.F16}[dtype]
+    N, H, W, Cc, K = (2, 16, 24, 256, 256) if case != "ragged" else (1, 10, 6, 128, 128)     # ragged: 60 pixels (< one 64-pixel tile), C = K = 128
+    x0 = torch.randn(N, Cc, H, W, generator=g)
+    if case == "out_down3":
+        ins = [x0, torch.randn(N, Cc, H, W, generator=g), torch.randn(N, Cc, 2 * H, 2 * W, generator=g)]
+        modes, wts = [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN], [0.31, 0.42, 0.27]
+    else:
+        ins = [x0, torch.randn(N, Cc, H // 2, W // 2, generator=g)]
+        modes, wts = [L.RES_ID, L.RES_UP_BILINEAR], [0.55, 0.45]
+    w = (torch.randn(K, Cc, generator=g) / Cc ** 0.5)
+    shift = torch.randn(K, generator=g) * 0.3
+    acts = [Act.of(nhwc(t).to(dtype)) for t in ins]
+    wd, sd = w.to(DEV).to(dtype), shift.to(DEV)
+    p = Plan(DEV)
+    s = p.new(N, H, W, Cc, code)
+    p.fuse(acts, wts, modes, s)
+    y2 = p.new(N, H, W, K, code)
+    p.conv(s, wd, y2, shift=sd, act=L.ACT_ELU)
+    y1 = p.new(N, H, W, K, code)
+    p.node(acts, wts, modes, wd, sd, y1, act=L.ACT_ELU)
+    run(p)
+    # the same fused map (rounded to the storage type exactly as the stand-alone kernel stores it) through the same MFMAs; only the order
+    # in which the 32-channel steps are accumulated may differ from the conv kernel's: a last-bit difference in a few elements at most
+    d = (y1.buf.float() - y2.buf.float()).abs()
+    ulp = y2.buf.float().abs().clamp_min(2.0 ** -6) * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+    assert (d <= ulp).all() and (d > 0).float().mean().item() < 0.02, (d.max().item(), (d > 0).float().mean().item())
+    # torch fp32 reference of the node
+    ref_in = [t.to(dtype).float() for t in ins]
+    parts = []
+    for t, m in zip(ref_in, modes):
+        if m == L.RES_UP_BILINEAR:
+            t = F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+        elif m == L.RES_DOWN_MEAN:
+            t = F.avg_pool2d(t, 2)
+        parts.append(t)
+    fused = sum(wv * t for wv, t in zip(wts, parts))
+    ref = F.elu(F.conv2d(fused, w.to(dtype).float()[:, :, None, None]) + shift[None, :, None, None])
+    rel = (back(y1.buf) - ref).norm().item() / ref.norm().item()
+    assert rel < (2e-2 if dtype == torch.bfloat16 else 3e-3), rel
