@@ -121,6 +121,32 @@ def train_main(args, world, rank, dev):
             for tag, plan, ms in (("fwd", tp.fwd, fwd_ms), ("bwd", ts.bwd, bwd_ms)):
                 for l, t in sorted(zip(plan.launches, ms), key=lambda p: -p[1])[:25]:
                     print(f"{tag} {t*1e3:9.1f} us  {l.flops/(t*1e-3)/1e12 if t > 0 else 0:7.1f} TF/s  {l.name}", file=sys.stderr)
+        # ---- per-family roofline of the step's kernels (HIP events around every launch of the two plans, single stream) ----
+        fam_of = {"mtbt_conv_wgrad": "wgrad", "mtbt_conv_wgrad_bias": "wgrad", "mtbt_stem_wgrad": "wgrad", "mtbt_conv2d_nhwc": "conv_fwd_dgrad",
+                  "mtbt_bn_forward_nhwc": "batchnorm", "mtbt_bn_forward_partials_nhwc": "batchnorm", "mtbt_bn_backward_nhwc": "batchnorm",
+                  "mtbt_dwconv_nhwc_train": "depthwise", "mtbt_dwconv_wgrad": "depthwise", "mtbt_dwconv_wgrad_bias": "depthwise",
+                  "mtbt_layernorm_nhwc": "layernorm", "mtbt_layernorm_backward_params_nhwc": "layernorm", "mtbt_channel_sum": "channel_sums",
+                  "mtbt_weight_prep": "weight_prep"}
+        fams = {}
+        for plan, ms_ in ((tp.fwd, fwd_ms), (ts.bwd, bwd_ms)):
+            for l, t in zip(plan.launches, ms_):
+                e = fams.setdefault(fam_of.get(getattr(l.fn, "__name__", ""), "other"), [0, 0.0, 0.0, 0.0])
+                e[0] += 1; e[1] += t; e[2] += l.flops; e[3] += l.bytes
+        traffic_fam = {}
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            if name.endswith("_train_traffic.json") and (B, S, args.dtype) == (32, 640, "bf16"):
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic_fam = {k: (round(v["traffic_bytes_per_launch"]), "profiles/" + name) for k, v in json.load(f).get("families", {}).items()}
+                break
+        peak_t = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        roofline_families = {}
+        for k, (n_, t_, fl, by) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
+            mfma = k in ("wgrad", "conv_fwd_dgrad")
+            ach = (fl / (t_ * 1e-3) / 1e12) if mfma else (by / (t_ * 1e-3) / 1e9)
+            roofline_families[k] = {"bound": "mfma" if mfma else "hbm", "launches_per_step": n_, "ms_per_step": round(t_, 3), "achieved": round(ach, 1),
+                                    "peak": peak_t if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / (peak_t if mfma else 8000.0), 4),
+                                    "algorithmic_bytes_per_launch": round(by / n_) if not mfma else None,
+                                    "traffic": traffic_fam.get(k, (None, None))[0], "traffic_source": traffic_fam.get(k, (None, None))[1]}
         flop_per_img = 545e9 * (S / 640.0) ** 2        # ~3x the 181.8 GFLOP forward
         ms_step = elapsed / args.steps * 1e3
         line = {"metric": "images/sec, training step (fwd + multitask loss + bwd + clip + optimizer) at 640x640", "value": round(world * B * args.steps / elapsed, 2),
@@ -133,7 +159,8 @@ def train_main(args, world, rank, dev):
                            "grad_norm": float(ts.gnorm.item()), "kept_activation_GiB": round(tp.fwd.pool.bytes / 2**30, 2)},
                 "roofline": {"bound": "mfma", "kernel": "whole training step (all kernels)", "achieved": round(B * flop_per_img / (ms_step * 1e-3) / 1e12, 2),
                              "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                             "frac": round(B * flop_per_img / (ms_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None}}
+                             "frac": round(B * flop_per_img / (ms_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None},
+                "roofline_families": roofline_families}
         print(json.dumps(line), flush=True)
 
 
@@ -149,6 +176,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="f16 = BASELINE configs[4]'s arithmetic (inference only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raw-heads", action="store_true", help="dev: skip the synthetic-head calibration (every anchor scores ~0.5: round 1-2's degenerate post-process load)")
+    ap.add_argument("--no-autotune", action="store_true", help="skip the launch-schedule search at start-up (GraphedInference(autotune=True))")
     ap.add_argument("--no-graph", action="store_true", help="issue the ~220 launches of a step eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", action="store_true", help="print per-layer timings to stderr")
     ap.add_argument("--ab-graph", default="", help="dev: comma list of VAR=val; each is re-lowered, re-captured and its graph replay timed")
@@ -205,7 +233,7 @@ def main():
         step = eager_step
     else:
         # the same step (drop-in forward + post-process), captured once into a HIP graph and replayed
-        graphed = GraphedInference(model, x, IMG)
+        graphed = GraphedInference(model, x, IMG, autotune=not args.no_autotune, log=(lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None)
         ref = unfused_step()
         torch.cuda.synchronize(dev)
         got = graphed.replay()
@@ -277,7 +305,11 @@ def main():
             ms = c.plan.run_timed()
             acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
         ms = [a / reps for a in acc]
-        conv = [(l, t) for l, t in zip(c.plan.launches, ms) if l.fn is c.plan.lib.mtbt_conv2d_nhwc]
+        # the MFMA conv family: the implicit-GEMM / direct conv kernels, the composed Proto upsample + cv2 kernel (its OWN FLOPs: 4/10 of the
+        # pair it replaces) and the BiFPN node kernel (the pointwise GEMM's FLOPs)
+        lib_ = c.plan.lib
+        conv_fns = (lib_.mtbt_conv2d_nhwc, lib_.mtbt_convt2x2_conv3x3_nhwc, lib_.mtbt_bifpn_node_nhwc)
+        conv = [(l, t) for l, t in zip(c.plan.launches, ms) if any(l.fn is f for f in conv_fns)]
         conv_flops = sum(l.flops for l, _ in conv)
         conv_ms = sum(t for _, t in conv)
         all_ms = sum(ms)
@@ -303,7 +335,7 @@ def main():
         conv_bytes = sum(l.bytes for l, _ in conv)
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         # the north star's 0.70 target is stated on the 3x3 kernels alone: their own FLOPs over their own time
-        c33 = [(l, t) for l, t in conv if l.keep[0].R == 3 and l.keep[0].S == 3]
+        c33 = [(l, t) for l, t in conv if l.fn is lib_.mtbt_convt2x2_conv3x3_nhwc or (l.fn is lib_.mtbt_conv2d_nhwc and l.keep[0].R == 3 and l.keep[0].S == 3)]
         f33, t33 = sum(l.flops for l, _ in c33), sum(t for _, t in c33)
         # HBM-class kernels (depthwise 7x7 + LayerNorm, depthwise 3x3, BiFPN fusion, LayerNorm2d, stem): algorithmic in + out bytes over their time
         hbm_fns = {"mtbt_dwconv_nhwc": "dwconv", "mtbt_bifpn_fuse": "bifpn_fuse", "mtbt_layernorm_nhwc": "layernorm", "mtbt_stem_conv4x4_ln": "stem"}
@@ -314,14 +346,14 @@ def main():
                 e = hbm.setdefault(k, [0.0, 0.0, 0])
                 e[0] += l.bytes; e[1] += t; e[2] += 1
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "f16") else 157.3
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_direct_kernel + conv3x3_rr_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_rr_kernel + upconv_fused_kernel + node_gemm_kernel (all tiles)", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(conv_bytes / len(conv)),
                     "launches_per_step": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
                     "flop_per_launch": round(conv_flops / len(conv)), "conv_ms_per_step": round(conv_ms, 3),
                     "all_kernels_ms_per_step": round(all_ms, 3)}
         peak_hbm = 8000.0
-        roofline_3x3 = {"bound": "mfma", "kernel": "conv3x3_direct_kernel + conv3x3_rr_kernel + conv_igemm_kernel on 3x3 shapes", "launches_per_step": len(c33),
+        roofline_3x3 = {"bound": "mfma", "kernel": "conv3x3_rr_kernel + conv_igemm_kernel on 3x3 shapes + upconv_fused_kernel (ConvT 2x2 o 3x3, its own FLOPs)", "launches_per_step": len(c33),
                         "achieved": round(f33 / (t33 * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(f33 / (t33 * 1e-3) / 1e12 / peak, 4),
                         "ms_per_step": round(t33, 3), "target_frac": 0.70}
         roofline_hbm = {k: {"bound": "hbm", "launches_per_step": v[2], "achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "peak": peak_hbm, "unit": "GB/s",

@@ -110,6 +110,27 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
         float t0[6], t1[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) { t0[c] = r0[c]; t1[c] = r1[c]; }
+        const long obase_m = (((long)n * p.K + g0 + b) * p.Hout + oy) * p.Wout + ox0;
+        if (!p.logits) {
+          // Masks only (the post-process path: 16 x 100 x 640^2 bytes per step, the largest single write of the step).  The kernel is
+          // VALU-bound, not HBM-bound (~140 vector instructions per 16 stored bytes in the logits form): so the vertical taps go FIRST --
+          // 6 columns x 2 + 16 pixels x 2 multiply-adds instead of 16 x 6 -- and the threshold + byte packing is one FMA and one
+          // v_cvt_pk_u8_f32 per pixel: (v - 2^-24) * 2^100 saturates to 255 above the threshold and to 0 at or below it.  The value
+          // differs from torch's horizontal-first association in the last bits only: the mask can differ where |logit| ~ 1e-7.
+          float v[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v[c] = wy0 * t0[c] + wy1 * t1[c];
+          unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ix = (e + 2) >> 2;                                   // compile-time
+            const float wx1 = ((e + 2) & 3) * 0.25f + 0.125f, wx0 = 1.0f - wx1;
+            const float val = wx0 * v[ix] + wx1 * v[ix + 1];
+            w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(val, 0x1p100f, -0x1p76f), e & 3, w[e >> 2]);
+          }
+          *reinterpret_cast<uint4*>(p.masks + obase_m) = uint4{w[0] & 0x01010101u, w[1] & 0x01010101u, w[2] & 0x01010101u, w[3] & 0x01010101u};
+          continue;
+        }
         float o[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {

@@ -7,8 +7,8 @@
 // kernels sit far below either roof (fusion 3.6 TB/s, the 256 -> 256 GEMM 0.08 of the MFMA peak / 0.18 of HBM).  Here the fusion arithmetic
 // IS the staging of the GEMM's B operand: a workgroup owns 64 consecutive pixels, its 256 threads compute s for them (16-byte pieces, fp32,
 // the stand-alone kernel's association order, rounded to the 16-bit storage type exactly as that kernel stores it -- so the result is
-// bit-identical to the two-launch form) straight into an XOR-swizzled [64 px][C] LDS image, then the four waves (2 channel halves x
-// 2 pixel halves) run the K x C GEMM with the weights streamed slab by slab (32 input channels, LDS-DMA, double-buffered) and the conv
+// equal to the two-launch form up to the accumulation order) straight into an XOR-swizzled [64 px][C] LDS image, then the four waves (one
+// quarter of the output channels each, all 64 pixels) run the K x C GEMM with their weight fragments already in registers and the conv
 // kernels' slab epilogue stores y.  HBM traffic per pixel: the inputs once + y once.
 #include "common.h"
 #include "conv_dma.h"
@@ -28,42 +28,29 @@ struct NodeP {
 // output nodes identity + identity + 2x2 mean): the fusion phase is then straight-line code whose 16-byte loads the compiler issues
 // four pieces ahead.  (With the modes behind run-time branches every piece waited for its own loads: 8 dependent round trips per
 // workgroup, 105 us for the P3 node where the two separate launches take 90.)
+// Weights: K = C <= 256, so the whole reduction is 4 or 8 steps of 32 channels.  A wave owns KT / 4 output channels x all 64 pixels and
+// loads ITS weight fragments for EVERY step straight from global memory into registers (a lane's 16-byte piece of a weight row IS its
+// MFMA A fragment; the 128 KB matrix is L2-resident, each row is read by exactly one wave of the workgroup) right behind the fusion
+// loads: they land while the fused map is computed, and the GEMM is then 32 .. 128 MFMAs per wave with nothing to wait for -- no weight
+// tiles in LDS, no barrier per reduction step.  (First version: 32-channel weight slabs through LDS-DMA, one barrier per step: 82 us.)
 template <typename T, int KT, int NIN, int M0, int M1, int M2>
 __global__ __launch_bounds__(256, 2) void node_gemm_kernel(const NodeP p) {
   constexpr int TP = 64;                          // pixels per workgroup
-  constexpr int ES = 2, BKB = 64;                 // 16-bit storage; weight slab = 32 input channels = 64 bytes per row
-  constexpr int FC = KT / 32, FP = 2, WCH = KT / 2;
-  constexpr int WSLAB = KT * BKB, WDMA = WSLAB / 16 / 256;
-  constexpr int CMAX = 256, BBYTES = TP * CMAX * ES;
-  static_assert(WDMA * 256 * 16 == WSLAB, "weight slab = whole wave-instructions");
-  static_assert(4 * 16 * (WCH * 4 + 16) <= BBYTES + 2 * WSLAB, "epilogue slabs below the affine copy");
+  constexpr int ES = 2;                           // 16-bit storage
+  constexpr int C = KT, rowb = C * ES;            // (square nodes only: C == K)
+  constexpr int WCH = KT / 4, FC = WCH / 16, FP = 4, NST = C / 32;
+  constexpr int BBYTES = TP * C * ES;
+  constexpr int PITCH = WCH * 4 + 16;
+  static_assert(4 * 16 * PITCH <= BBYTES, "epilogue slabs inside the B image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bimg = smem;                              // [TP][C] T, 16-byte slot c8 of pixel q at q * C * 2 + ((c8 ^ (q & 15)) << 4) (low four slot bits)
-  float* aff = reinterpret_cast<float*>(smem + BBYTES + 2 * WSLAB);
+  float* aff = reinterpret_cast<float*>(smem + BBYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 1, wr = wave >> 1;
   const int lr = lane & 15, lq = lane >> 4;
-  constexpr int C = KT, rowb = C * ES;            // (square nodes only: C == K)
   const long M = (long)p.f.N * p.f.H * p.f.W;
   const long pix0 = (long)blockIdx.x * TP;
   stage_affine<KT>(p.ep, aff, 0, tid);
-
-  // ---- weights: slab 0 on its way while the fusion runs ----
-  const srd_t wsrd = make_srd(p.w);
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  unsigned wvoff[WDMA];
-#pragma unroll
-  for (int i = 0; i < WDMA; ++i) {
-    const int c = i * 256 + tid;
-    const int row = c >> 2, sl = c & 3;
-    wvoff[i] = (unsigned)((row * C + (sl ^ ((row >> 2) & 3)) * 8) * ES);
-  }
-  auto stage_w = [&](int g) {
-#pragma unroll
-    for (int i = 0; i < WDMA; ++i) lds_dma16(wsrd, wvoff[i], g * BKB, lds0 + BBYTES + (g & 1) * WSLAB + (i * 256 + wave * 64) * 16);
-  };
-  stage_w(0);
 
   // ---- B operand = the fused map of this workgroup's pixels ----
   constexpr int CH8 = C >> 3, PCS = TP * CH8 / 256;
@@ -93,45 +80,42 @@ __global__ __launch_bounds__(256, 2) void node_gemm_kernel(const NodeP p) {
     st8<T>(reinterpret_cast<T*>(bimg + q * rowb + ((((c8 & 15) ^ (q & 15)) | (c8 & ~15)) << 4)), acc);
   }
 
+  // ---- this wave's weight fragments for the whole reduction: rows wave * WCH + f * 16 + lr, 16-byte piece (step g, quarter lq) ----
+  uint4 a[NST][FC];
+  {
+    const T* wrow = reinterpret_cast<const T*>(p.w) + (long)(wave * WCH + lr) * C + lq * 8;
+#pragma unroll
+    for (int g = 0; g < NST; ++g)
+#pragma unroll
+      for (int f = 0; f < FC; ++f) a[g][f] = *reinterpret_cast<const uint4*>(wrow + (long)f * 16 * C + g * 32);
+  }
+  __syncthreads();   // the whole B image is written
+
   f32x4 acc[FC][FP];
 #pragma unroll
   for (int i = 0; i < FC; ++i)
 #pragma unroll
     for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int arow = wc * WCH + lr;
-  const int aoff = BBYTES + arow * BKB + ((lq ^ ((arow >> 2) & 3)) << 4);      // + buf * WSLAB + f * 16 * BKB
-  const int nsteps = C / 32;
-#pragma unroll 1
-  for (int g0 = 0; g0 < nsteps; g0 += 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {      // buffer parity compile-time
-      const int g = g0 + u;
-      if (g >= nsteps) continue;       // (odd slab count: uniform over the block)
-      wait_vm<0>();                    // my pieces of slab g have landed
-      lds_barrier();                   // everyone's have (first pass: and the whole B image is written); the other buffer is free
-      if (g + 1 < nsteps) stage_w(g + 1);
-      uint4 a[FC], b[FP];
+  for (int g = 0; g < NST; ++g) {
+    uint4 b[FP];
 #pragma unroll
-      for (int j = 0; j < FP; ++j) {
-        const int q = wr * 32 + j * 16 + lr;
-        const int slot = g * 4 + lq;
-        b[j] = *reinterpret_cast<const uint4*>(bimg + q * rowb + ((((slot & 15) ^ (q & 15)) | (slot & ~15)) << 4));
-      }
-      const char* wb = smem + aoff + u * WSLAB;
-#pragma unroll
-      for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const uint4*>(wb + f * 16 * BKB);
-#pragma unroll
-      for (int i = 0; i < FC; ++i)
-#pragma unroll
-        for (int j = 0; j < FP; ++j) acc[i][j] = mfma_16x16x32<T>(a[i], b[j], acc[i][j]);
+    for (int j = 0; j < FP; ++j) {
+      const int q = j * 16 + lr;
+      const int slot = g * 4 + lq;
+      b[j] = *reinterpret_cast<const uint4*>(bimg + q * rowb + ((((slot & 15) ^ (q & 15)) | (slot & ~15)) << 4));
     }
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j) acc[i][j] = mfma_16x16x32<T>(a[g][i], b[j], acc[i][j]);
   }
-  __syncthreads();   // LDS below the affine copy is free for the epilogue slabs
+  __syncthreads();   // every wave is done with the B image: its LDS is reused for the epilogue slabs
 
-  const EpiSeq seq{pix0 + wr * 32, 16, M, 0L, 0L};
-  conv_epilogue<T, KT, FC, FP, false>(p.ep, acc, smem + wave * (16 * (WCH * 4 + 16)), aff, 0, wc * WCH, lane,
+  const EpiSeq seq{pix0, 16, M, 0L, 0L};
+  conv_epilogue<T, KT, FC, FP, false>(p.ep, acc, smem + wave * (16 * PITCH), aff, 0, wave * WCH, lane,
                                       [&](int j, int row, int ch, long& yoff, long& roff) -> bool {
-    const long pix = pix0 + wr * 32 + j * 16 + row;
+    const long pix = pix0 + j * 16 + row;
     yoff = pix * p.ep.ldy + ch;
     roff = 0;
     return pix < M;
@@ -143,7 +127,7 @@ int launch_node_t(const NodeP& p, hipStream_t s) {
   const long M = (long)p.f.N * p.f.H * p.f.W;
   const long blocks = (M + 63) / 64;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  constexpr int lds = 64 * 256 * 2 + 2 * KT * 64 + 2 * KT * 4;
+  constexpr int lds = 64 * KT * 2 + 2 * KT * 4;
   if (int rc = mtbt_allow_lds(node_gemm_kernel<T, KT, NIN, M0, M1, M2>, lds)) return rc;
   hipLaunchKernelGGL((node_gemm_kernel<T, KT, NIN, M0, M1, M2>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   MTBT_LAUNCH_CHECK();

@@ -104,6 +104,7 @@ class Launch:
     bytes: float = 0.0
     reads: tuple = ()   # memory regions (see _region) this launch reads / writes: the scheduler's dependency source
     writes: tuple = ()
+    side: bool = False  # scheduler hint: off the main chain (lane 0) whenever a side lane is allowed -- branch work lowered EARLY in program order
 
 
 def _region(a):
@@ -317,6 +318,8 @@ class Plan:
                 allowed = range(n_lanes)
             else:
                 allowed = range(n_lanes) if not side else ([0] + list(side) if len(side) == 1 else [0])
+            if l.side and n_lanes > 1 and any(k != 0 for k in allowed):
+                allowed = [k for k in allowed if k != 0]   # (in program order the main chain's next launches come later: lane 0 looks free now)
             best = min(allowed, key=lambda k: (max(ready, free[k]), k))
             if crit >= 0 and lane[crit] in allowed and free[lane[crit]] <= max(ready, free[best]) + 1e-9:
                 best = lane[crit]

@@ -11,9 +11,51 @@ import torch
 from . import postprocess as pp
 
 
+# Schedule candidates of `autotune`: (plan option, values).  Coordinate search from the defaults: one knob at a time, keep what is faster.
+AUTOTUNE_KNOBS = (("NODE_FUSED", ("1",)), ("SEG_GATE", ("1", "2")), ("LANE_WIDE_US", ("200",)), ("LANES", ("3",)), ("ADAPTOR_EARLY", ("1",)),
+                  ("HEADS_EARLY", ("1",)))
+
+
 class GraphedInference:
     def __init__(self, model, x: torch.Tensor, img_size: int, conf_th=pp.CONF_TH, iou_th=pp.NMS_IOU, top_k=pp.TOP_K, masks=True,
-                 warmup: int = 2):
+                 warmup: int = 2, autotune: bool = False, log=None):
+        """`autotune`: before the final capture, time a few launch SCHEDULES of the same plan (lane count, which branches are issued early
+        or gated, fused / two-launch BiFPN nodes: `model.plan_option`) as captured graphs -- a dozen replays each -- and keep the fastest
+        in `model.plan_options`.  Why: the step is ~190 launches on four streams; which independent chains the GPU happens to run side by
+        side moves the replay time by +-4 % (a fused kernel that is 15 % faster alone made the step 0.24 ms SLOWER because the prototype
+        chain then started later), nothing of which a static cost model sees.  Results do not depend on the schedule."""
+        if autotune:
+            import time
+            opts = dict(model.__dict__.get("plan_options", {}))
+
+            def timed(o):
+                model.plan_options = o
+                g = GraphedInference(model, x, img_size, conf_th, iou_th, top_k, masks, warmup=1)
+                for _ in range(3):
+                    g.replay()
+                torch.cuda.synchronize(x.device)
+                t0 = time.perf_counter()
+                for _ in range(12):
+                    g.replay()
+                torch.cuda.synchronize(x.device)
+                dt = (time.perf_counter() - t0) / 12
+                del g
+                return dt
+            best = timed(dict(opts))
+            if log:
+                log(f"autotune: defaults {best * 1e3:.3f} ms")
+            for name, values in AUTOTUNE_KNOBS:
+                for v in values:
+                    cand = dict(opts, **{name: v})
+                    t = timed(cand)
+                    if log:
+                        log(f"autotune: {name}={v} {t * 1e3:.3f} ms" + (" *" if t < best * 0.995 else ""))
+                    if t < best * 0.995:
+                        best, opts = t, cand
+            model.plan_options = opts
+            model.__dict__.get("_plans", {}).clear()          # the losers' plans hold buffer pools
+            if log:
+                log(f"autotune: kept {opts} ({best * 1e3:.3f} ms)")
         if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError("GraphedInference needs a contiguous fp32 CUDA/HIP batch [B,3,S,S] (it is read in place)")
         self.model, self.x = model, x

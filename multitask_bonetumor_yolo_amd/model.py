@@ -245,6 +245,19 @@ def compose_upconv(wt: torch.Tensor, bt: torch.Tensor, w3: torch.Tensor, scale: 
     return w.reshape(4 * K, 4 * Ci).float(), shift9.float()
 
 
+PLAN_OPTION_DEFAULTS = {"NODE_FUSED": "0", "ADAPTOR_EARLY": "0", "HEADS_EARLY": "0", "SEG_GATE": "0", "LANES": None, "LANE_WIDE_US": None}
+
+
+def plan_option(model, name: str):
+    """A scheduling / lowering knob of the inference plan: `model.plan_options[name]` (set by `GraphedInference(autotune=True)`, which times a
+    few combinations and keeps the fastest) > the environment variable MTBT_<name> (development A/B) > the default.  Every combination
+    computes the same values up to the fused kernels' accumulation order; only the launch schedule differs."""
+    v = model.__dict__.get("plan_options", {}).get(name)
+    if v is None:
+        v = os.environ.get("MTBT_" + name, PLAN_OPTION_DEFAULTS[name])
+    return v
+
+
 class _Lowering:
     """Builds the launch plan for one (batch, size, dtype, mode) from the module tree."""
 
@@ -369,17 +382,34 @@ class _Lowering:
 
     # -- backbone (main_model.py:33-38) --
     def backbone(self):
+        """ConvNeXt-T stages with each C2f adaptor lowered RIGHT BEHIND the stage that feeds it (plan option ADAPTOR_EARLY=1; default 0: after the whole body,
+        as the reference writes it, main_model.py:33-38).  The adaptors depend on one stage output each, so they are side-lane work either
+        way; but launches are issued -- and captured into the HIP graph -- in program order, and with the adaptors at the end the P3
+        adaptor's first kernel started 1 ms after its input existed (timeline of the replayed graph: beside stage 2's seventh block).
+        Stage 2 fills 200 of the 256 CUs and stage 3 far fewer: issued early, c2f_p3 / c2f_p4 run in that slack."""
         bb = self.m.backbone
-        feats = self.features(bb.body)
-        c3 = self.c2f(feats[0], bb.c2f_p3, "backbone.c2f_p3")
-        c4 = self.c2f(feats[1], bb.c2f_p4, "backbone.c2f_p4")
-        c5 = self.c2f(feats[2], bb.c2f_p5, "backbone.c2f_p5")
+        early = plan_option(self.m, "ADAPTOR_EARLY") == "1"
+        mods = {1: (bb.c2f_p3, "backbone.c2f_p3"), 2: (bb.c2f_p4, "backbone.c2f_p4"), 3: (bb.c2f_p5, "backbone.c2f_p5")}
+        outs = {}
+
+        def hook(si, a):
+            if early:
+                first = len(self.p.launches)
+                outs[si] = self.c2f(a, *mods[si])
+                if si < 3:                       # (the last adaptor has nothing left to hide under: it continues the main chain)
+                    for l in self.p.launches[first:]:
+                        l.side = True
+        feats = self.features(bb.body, hook)
+        if not early:
+            for si in (1, 2, 3):
+                outs[si] = self.c2f(feats[si - 1], *mods[si])
         for f in feats:
             self.p.release(f)
-        return c3, c4, c5
+        return outs[1], outs[2], outs[3]
 
-    def features(self, body):
-        """timm ConvNeXt-T feature extractor: outputs of stages 1..3 (live buffers; the caller releases them)."""
+    def features(self, body, on_feature=None):
+        """timm ConvNeXt-T feature extractor: outputs of stages 1..3 (live buffers; the caller releases them).  `on_feature(si, act)` is called
+        as soon as stage si's output has been lowered."""
         N, _, H, W = self.x.shape
         a = self.p.new(N, H // 4, W // 4, DIMS[0], self.code)
         self.p.stem(self.x, self.F(body.stem_0.weight.detach().reshape(DIMS[0], 48)), self.F(body.stem_0.bias),
@@ -439,6 +469,8 @@ class _Lowering:
             a = out_full
             if si >= 1:
                 feats.append(a)      # stage outputs 1..3 stay live until the adaptors have read them
+                if on_feature is not None:
+                    on_feature(si, a)
         return feats
 
     # -- neck of the oldest variant (src/model.py:27-93): lateral Convs, WeightedAdd (adds its weights), DWConv 3x3 nodes --
@@ -476,7 +508,9 @@ class _Lowering:
         w = torch.nn.functional.elu(w.detach().float().cpu())
         return w / (w.sum(dim=0, keepdim=True) + eps)
 
-    def neck(self, c3, c4, c5):
+    def neck(self, c3, c4, c5, on_level=None):
+        """`on_level(i, act)`: called as soon as the LAST unit has produced pyramid level i (order: P3, P4, P5 -- the top-down P3 node
+        finishes first), so that the heads of that level can be lowered (and issued) before the rest of the neck."""
         nk = self.m.neck
         p3 = self.convblock(c3, nk.p3_proj, None, "neck.p3_proj")
         p4 = self.convblock(c4, nk.p4_proj, None, "neck.p4_proj")
@@ -491,7 +525,7 @@ class _Lowering:
                 K = conv.pointwise.out_channels
                 shapes = ([L.RES_ID, L.RES_UP_BILINEAR], [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN])
                 if (self.code in (L.BF16, L.F16) and like.C in (128, 256) and K == like.C and list(modes) in shapes and not conv.bn.training
-                        and os.environ.get("MTBT_NODE_FUSED", "1") == "1"):
+                        and plan_option(self.m, "NODE_FUSED") == "1"):
                     # weighted sum + resample + DepthwiseConvBlock (scale folded, BN folded, ELU) in ONE launch: the fused map never reaches HBM
                     dw = conv.depthwise.weight.detach().float().reshape(1, -1)
                     pw = conv.pointwise.weight.detach().float().reshape(K, -1) * dw
@@ -508,12 +542,19 @@ class _Lowering:
                 self.p.release(d)
                 return o
 
+            last = on_level is not None and ui == len(nk.bifpn_units) - 1
             p4_td = node([p4, p5], [a[0, 0], a[1, 0]], [L.RES_ID, L.RES_UP_BILINEAR], p4, u.p4_td_conv, u.p4_td_cf, "p4_td")
             p3_td = node([p3, p4_td], [a[0, 1], a[1, 1]], [L.RES_ID, L.RES_UP_BILINEAR], p3, u.p3_td_conv, u.p3_td_cf, "p3_td")
+            if last:
+                on_level(0, p3_td)
             p4_out = node([p4, p4_td, p3_td], [b[0, 0], b[1, 0], b[2, 0]], [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN], p4,
                           u.p4_out_conv, u.p4_out_cf, "p4_out")
+            if last:
+                on_level(1, p4_out)
             p5_out = node([p5, p5, p4_out], [b[0, 1], b[1, 1], b[2, 1]], [L.RES_ID, L.RES_ID, L.RES_DOWN_MEAN], p5,
                           u.p5_out_conv, u.p5_out_cf, "p5_out")
+            if last:
+                on_level(2, p5_out)
             for t in (p3, p4, p5, p4_td):
                 self.p.release(t)
             p3, p4, p5 = p3_td, p4_out, p5_out
@@ -523,51 +564,71 @@ class _Lowering:
     def f32_out(self, N, H, W, Cc) -> Act:
         return Act.of(torch.empty((N, H, W, Cc), dtype=torch.float32, device=self.x.device))
 
-    def det_branch(self, feats, head: Detect, tag):
-        """cv2 (box, 4*reg_max ch) and cv3 (cls, nc ch) write side by side into one [N,h,w,no] fp32 map
-        (the `torch.cat((cv2_i, cv3_i), 1)` of Detect.forward without the copy)."""
-        maps = []
-        for i, f in enumerate(feats):
-            # pixel pitch rounded up to 4 floats (66 -> 68): the 64-channel box slice then starts every pixel on a 16-byte boundary and the
-            # conv epilogue stores it with 16-byte accesses (at pitch 66 it fell back to 64 scalar stores per pixel: 43 us per P3 map, 0.11 of HBM)
-            ld = (head.no + 3) // 4 * 4
-            buf = torch.empty((f.N, f.H, f.W, ld), dtype=torch.float32, device=self.x.device)
-            full = Act(buf, 0, f.N, f.H, f.W, head.no, ld, f.H * f.W * ld)
-            s = head.cv2[i]
-            t1 = self.convblock(f, s[0], None, f"{tag}.cv2.{i}.0")
-            t2 = self.convblock(t1, s[1], None, f"{tag}.cv2.{i}.1")
-            self.p.release(t1)
-            self.conv_plain(t2, s[2], full.slice(0, 4 * head.reg_max), f"{tag}.cv2.{i}.2")
-            self.p.release(t2)
-            s = head.cv3[i]
-            d1 = self.dwblock(f, s[0][0], f"{tag}.cv3.{i}.0.0")
-            t1 = self.convblock(d1, s[0][1], None, f"{tag}.cv3.{i}.0.1")
-            self.p.release(d1)
-            d2 = self.dwblock(t1, s[1][0], f"{tag}.cv3.{i}.1.0")
-            self.p.release(t1)
-            t2 = self.convblock(d2, s[1][1], None, f"{tag}.cv3.{i}.1.1")
-            self.p.release(d2)
-            self.conv_plain(t2, s[2], full.slice(4 * head.reg_max, head.nc), f"{tag}.cv3.{i}.2")
-            self.p.release(t2)
-            maps.append(full)
-        return maps
+    def det_level(self, i, f: Act, head: Detect, tag, gate=None) -> Act:
+        """Level i of Detect.forward: cv2 (box, 4*reg_max ch) and cv3 (cls, nc ch) write side by side into one [N,h,w,no] fp32 map
+        (the `torch.cat((cv2_i, cv3_i), 1)` of Detect.forward without the copy).
+        `gate`: activations / tensors the first launch of each of the two chains is made to WAIT for (recorded as extra reads, i.e.
+        ordinary read-after-write edges for the lane scheduler): the caller's way of keeping a branch nobody is waiting for off the
+        machine until the branches on the post-process's critical path are through."""
+        from .engine import _region
 
-    def seg_extras(self, feats, head: Segment):
-        """Mask coefficients (cv4, all levels into one [N,A,nm] buffer) and prototypes (Proto on P3)."""
-        N = feats[0].N
-        A = sum(f.H * f.W for f in feats)
-        mc = torch.empty((N, A, head.nm), dtype=torch.float32, device=self.x.device)
-        off = 0
-        for i, f in enumerate(feats):
-            s = head.cv4[i]
-            t1 = self.convblock(f, s[0], None, f"segment.cv4.{i}.0")
-            t2 = self.convblock(t1, s[1], None, f"segment.cv4.{i}.1")
-            self.p.release(t1)
-            lvl = Act(mc, off * head.nm, N, f.H, f.W, head.nm, head.nm, A * head.nm)
-            self.conv_plain(t2, s[2], lvl, f"segment.cv4.{i}.2")
-            self.p.release(t2)
-            off += f.H * f.W
-        pr, f = head.proto, feats[0]
+        def gated(first):
+            if gate:
+                l = self.p.launches[first]
+                l.reads = l.reads + tuple(_region(g) for g in gate)
+        # pixel pitch rounded up to 4 floats (66 -> 68): the 64-channel box slice then starts every pixel on a 16-byte boundary and the
+        # conv epilogue stores it with 16-byte accesses (at pitch 66 it fell back to 64 scalar stores per pixel: 43 us per P3 map, 0.11 of HBM)
+        ld = (head.no + 3) // 4 * 4
+        buf = torch.empty((f.N, f.H, f.W, ld), dtype=torch.float32, device=self.x.device)
+        full = Act(buf, 0, f.N, f.H, f.W, head.no, ld, f.H * f.W * ld)
+        # the class chain (two depthwise + two 1x1 + output conv) is the longer one: first
+        s = head.cv3[i]
+        first = len(self.p.launches)
+        d1 = self.dwblock(f, s[0][0], f"{tag}.cv3.{i}.0.0")
+        gated(first)
+        t1 = self.convblock(d1, s[0][1], None, f"{tag}.cv3.{i}.0.1")
+        self.p.release(d1)
+        d2 = self.dwblock(t1, s[1][0], f"{tag}.cv3.{i}.1.0")
+        self.p.release(t1)
+        t2 = self.convblock(d2, s[1][1], None, f"{tag}.cv3.{i}.1.1")
+        self.p.release(d2)
+        self.conv_plain(t2, s[2], full.slice(4 * head.reg_max, head.nc), f"{tag}.cv3.{i}.2")
+        self.p.release(t2)
+        s = head.cv2[i]
+        first = len(self.p.launches)
+        t1 = self.convblock(f, s[0], None, f"{tag}.cv2.{i}.0")
+        gated(first)
+        t2 = self.convblock(t1, s[1], None, f"{tag}.cv2.{i}.1")
+        self.p.release(t1)
+        self.conv_plain(t2, s[2], full.slice(0, 4 * head.reg_max), f"{tag}.cv2.{i}.2")
+        self.p.release(t2)
+        return full
+
+    def det_branch(self, feats, head: Detect, tag, gate=None):
+        return [self.det_level(i, f, head, tag, gate[i] if gate is not None else None) for i, f in enumerate(feats)]
+
+    def mc_buffer(self, shapes, head: Segment):
+        """[N, A, nm] fp32 buffer of the mask coefficients of all levels + the anchor offset of every level."""
+        N = shapes[0][0]
+        A = sum(h * w for _, h, w in shapes)
+        offs, off = [], 0
+        for _, h, w in shapes:
+            offs.append(off)
+            off += h * w
+        return torch.empty((N, A, head.nm), dtype=torch.float32, device=self.x.device), offs, A
+
+    def cv4_level(self, i, f: Act, head: Segment, mc: torch.Tensor, off: int, A: int):
+        s = head.cv4[i]
+        t1 = self.convblock(f, s[0], None, f"segment.cv4.{i}.0")
+        t2 = self.convblock(t1, s[1], None, f"segment.cv4.{i}.1")
+        self.p.release(t1)
+        lvl = Act(mc, off * head.nm, f.N, f.H, f.W, head.nm, head.nm, A * head.nm)
+        self.conv_plain(t2, s[2], lvl, f"segment.cv4.{i}.2")
+        self.p.release(t2)
+
+    def proto(self, f: Act, head: Segment) -> Act:
+        """ultralytics Proto on P3: cv1 3x3 -> upsample (ConvTranspose 2x2 / 2) -> cv2 3x3 -> cv3 1x1."""
+        pr = head.proto
         t1 = self.convblock(f, pr.cv1, None, "segment.proto.cv1")
         if (not pr.cv2.bn.training and f.H % 16 == 0 and f.W % 16 == 0 and pr.cv2.conv.out_channels % 128 == 0
                 and os.environ.get("MTBT_PROTO_FUSED", "1") == "1"):
@@ -578,21 +639,25 @@ class _Lowering:
             t2 = self.p.new(f.N, 2 * f.H, 2 * f.W, pr.cv2.conv.out_channels, self.code)
             self.p.upconv(t1, self.W(wc), self.F(shift9), t2, act=L.ACT_SILU, name="segment.proto.upsample+cv2")
             self.p.release(t1)
-            protos = self.f32_out(f.N, 2 * f.H, 2 * f.W, head.nm)
-            self.convblock(t2, pr.cv3, protos, "segment.proto.cv3")
-            self.p.release(t2)
-            return mc, protos
-        up = self.p.new(f.N, 2 * f.H, 2 * f.W, pr.upsample.out_channels, self.code)
-        wt = pr.upsample.weight.detach()  # [Cin, Cout, 2, 2] -> GEMM rows (dy*2+dx)*Cout + co
-        self.p.conv(t1, self.W(wt.permute(2, 3, 1, 0).reshape(4 * wt.shape[1], wt.shape[0])), up,
-                    shift=self.F(pr.upsample.bias.detach().repeat(4)), out_mode=L.OUT_CONVT2X2, name="segment.proto.upsample")
-        self.p.release(t1)
-        t2 = self.convblock(up, pr.cv2, None, "segment.proto.cv2")
-        self.p.release(up)
+        else:
+            up = self.p.new(f.N, 2 * f.H, 2 * f.W, pr.upsample.out_channels, self.code)
+            wt = pr.upsample.weight.detach()  # [Cin, Cout, 2, 2] -> GEMM rows (dy*2+dx)*Cout + co
+            self.p.conv(t1, self.W(wt.permute(2, 3, 1, 0).reshape(4 * wt.shape[1], wt.shape[0])), up,
+                        shift=self.F(pr.upsample.bias.detach().repeat(4)), out_mode=L.OUT_CONVT2X2, name="segment.proto.upsample")
+            self.p.release(t1)
+            t2 = self.convblock(up, pr.cv2, None, "segment.proto.cv2")
+            self.p.release(up)
         protos = self.f32_out(f.N, 2 * f.H, 2 * f.W, head.nm)
         self.convblock(t2, pr.cv3, protos, "segment.proto.cv3")
         self.p.release(t2)
-        return mc, protos
+        return protos
+
+    def seg_extras(self, feats, head: Segment):
+        """Mask coefficients (cv4, all levels into one [N,A,nm] buffer) and prototypes (Proto on P3)."""
+        mc, offs, A = self.mc_buffer([(f.N, f.H, f.W) for f in feats], head)
+        for i, f in enumerate(feats):
+            self.cv4_level(i, f, head, mc, offs[i], A)
+        return mc, self.proto(feats[0], head)
 
     def cls_head(self, n5: Act):
         logits = torch.empty((n5.N, self.m.cls_fc.out_features), dtype=torch.float32, device=self.x.device)
@@ -681,7 +746,8 @@ class _Base(nn.Module):
         # one plan per BatchNorm-mode tuple: alternating forward(x, "infer") and forward(x, "train") (validation: heads on batch
         # statistics) no longer evict each other, and a train-mode call does not invalidate its own plan
         bn_modes = tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
-        key = (tuple(x.shape), self.compute_dtype, x.device.index, bn_modes)
+        opts = tuple(plan_option(self, k) for k in sorted(PLAN_OPTION_DEFAULTS))
+        key = (tuple(x.shape), self.compute_dtype, x.device.index, bn_modes, opts)
         sig = self._weights_sig(bn_modes)
         cache = self.__dict__.setdefault("_plans", {})
         if len(cache) > 8:                                # bounded: stale (shape, mode) plans hold buffer pools
@@ -692,23 +758,57 @@ class _Base(nn.Module):
         with torch.no_grad():
             xs = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
             lo = _Lowering(self, xs, code_of(self.compute_dtype))
+            if plan_option(self, "LANES") is not None:
+                lo.p.n_lanes = max(1, int(plan_option(self, "LANES")))
+            if plan_option(self, "LANE_WIDE_US") is not None:
+                lo.p.lane_wide_s = float(plan_option(self, "LANE_WIDE_US")) * 1e-6
+            has_det = hasattr(self, "detect")
+            det_maps = [None] * 3 if has_det else None
+            seg_maps = [None] * 3
+            state = {}
+            gate_mode = int(plan_option(self, "SEG_GATE"))
+            early = plan_option(self, "HEADS_EARLY") == "1" and not isinstance(self, ConvNeXtBiFPNYOLOv0)
+
+            def heads_of_level(i, f, shapes):
+                """Everything that hangs off pyramid level i, in the order of what the post-process waits for: the prototype chain (the
+                longest, P3 only), Detect's branches (decode -> NMS), the mask coefficients, then Segment's own box / class branches
+                (they feed `segment_preds_cat` only: optionally gated behind Detect's map of the level, MTBT_SEG_GATE=1)."""
+                # the head branches are independent: no buffer recycling between them, so the lane scheduler sees no false dependencies
+                keep = lo.p.pool.reuse
+                lo.p.pool.reuse = keep and os.environ.get("MTBT_HEAD_REUSE", "0") == "1"
+                first = len(lo.p.launches)
+                if "mc" not in state:
+                    state["mc"], state["offs"], state["A"] = lo.mc_buffer(shapes, self.segment)
+                if i == 0:
+                    state["protos"] = lo.proto(f, self.segment)
+                if has_det:
+                    det_maps[i] = lo.det_level(i, f, self.detect, "detect")
+                lo.cv4_level(i, f, self.segment, state["mc"], state["offs"][i], state["A"])
+                gate = [det_maps[i]] if (has_det and gate_mode >= 1) else None
+                seg_maps[i] = lo.det_level(i, f, self.segment, "segment", gate)
+                if early:                         # lowered in the middle of the neck: branch work, off the neck's main chain
+                    for l in lo.p.launches[first:]:
+                        l.side = True
+                lo.p.pool.reuse = keep
+
+            S_ = x.shape[2]
+            shapes = [(x.shape[0], S_ // 8, x.shape[3] // 8), (x.shape[0], S_ // 16, x.shape[3] // 16), (x.shape[0], S_ // 32, x.shape[3] // 32)]
             if isinstance(self, ConvNeXtBiFPNYOLOv0):
                 n3, n4, n5 = lo.neck_v0(*lo.features(self.backbone.body))
             else:
                 c3, c4, c5 = lo.backbone()
-                n3, n4, n5 = lo.neck(c3, c4, c5)
+                # MTBT_HEADS_EARLY (default): the heads of a pyramid level are lowered -- and therefore issued / captured -- the moment the
+                # LAST BiFPN unit has produced that level.  P3 comes first (top-down node), and P3 carries most of the head work (the
+                # prototype chain, the 80x80 branches): it then runs beside the unit's P4 / P5 output nodes, small launches that leave most
+                # of the machine idle, instead of queueing behind them; and the chains the post-process waits for (prototypes, Detect)
+                # are first in line.  (Round 2 lowered all heads after the neck, Detect -> cv4 -> Proto -> Segment: in the replayed graph
+                # the prototype chain started up to 0.6 ms after its input existed and the mask assembly waited for it at the end.)
+                n3, n4, n5 = lo.neck(c3, c4, c5, on_level=(lambda i, f: heads_of_level(i, f, shapes)) if early else None)
             feats = [n3, n4, n5]
-            # the head branches (3 levels x detect / segment / cv4 + Proto) are independent: no buffer recycling between
-            # them, so the lane scheduler (engine.Plan.schedule) sees no false write-after-read dependencies
-            lo.p.pool.reuse = lo.p.pool.reuse and os.environ.get("MTBT_HEAD_REUSE", "0") == "1"
-            # order: Detect first (its maps start the box decode + NMS on a side stream), then the mask coefficients and prototypes (with
-            # the kept boxes they start the mask assembly, which then runs UNDER Segment's own box / class branches and the cls head)
-            det_maps = lo.det_branch(feats, self.detect, "detect") if hasattr(self, "detect") else None
-            if det_maps is None:
-                seg_maps = lo.det_branch(feats, self.segment, "segment")
-            mc, protos = lo.seg_extras(feats, self.segment)
-            if det_maps is not None:
-                seg_maps = lo.det_branch(feats, self.segment, "segment")
+            if not early:
+                for i, f in enumerate(feats):
+                    heads_of_level(i, f, [(t.N, t.H, t.W) for t in feats])
+            mc, protos = state["mc"], state["protos"]
             logits = lo.cls_head(n5)
         c = _Compiled(lo.p, xs, det_maps, seg_maps, mc, protos, logits, sig)
         # launches that write the maps the box decode reads: the post-process forks as soon as these are done
@@ -1024,12 +1124,20 @@ def calibrate_synthetic_heads_(model: nn.Module, x: torch.Tensor, cand_frac: flo
     bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
     saved = [(m.momentum, m.training) for m in bns]
     flags = [(m, m.training) for m in model.modules()]
+    dt_state = (model.__dict__.get("_dtype"), model.__dict__.get("_dtype_explicit"))
     try:
         for m in bns:
             m.momentum = 1.0
+        if model.compute_dtype == torch.float16:     # (fp16 is an inference mode: the statistics pass runs in bf16)
+            model.set_compute_dtype(torch.bfloat16)
         model.train()
         model(x, "train")
     finally:
+        for key, v in zip(("_dtype", "_dtype_explicit"), dt_state):
+            if v is None:
+                model.__dict__.pop(key, None)
+            else:
+                model.__dict__[key] = v
         for m, (mom, _) in zip(bns, saved):
             m.momentum = mom
         for m, tr in flags:
