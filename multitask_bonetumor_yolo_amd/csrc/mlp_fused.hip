@@ -339,6 +339,171 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Wide d (384): the PAIR form.  In the kernel above a wave carries its 32 pixels alone: 192 accumulator + 96 input registers leave room for
+// ONE wave per SIMD, and at one wave per SIMD nothing covers an LDS fragment read, a GELU or the wait at a barrier -- its MFMA phases run
+// at ~58 % of the matrix pipe's rate (ISA of round 3: every fragment read is waited for one or two MFMAs later) and skeleton, weight DMA,
+// GELU and MFMA time simply add up (127 us per call where the MFMAs alone need 35).  Here TWO waves share a 32-pixel block:
+//   * GEMM1: wave hh of the pair computes hidden rows 16 hh .. 16 hh + 15 of the chunk (half of the chunk's MFMAs);
+//   * GELU on its 4 + 4 values, packed: these are the .xy (hh = 0) or .zw (hh = 1) words of GEMM2's B fragment FOR THE SAME LANE of both
+//     waves, so the exchange is 8 bytes per lane and pixel block through LDS, published by the chunk's barrier;
+//   * GEMM2: wave hh accumulates output channels hh * d/2 .. (hh + 1) * d/2 - 1 (half the accumulators: 96 registers).
+// 8 waves per workgroup = TWO per SIMD (<= 256 registers each), and inside a wave the loop is skewed by one chunk -- iteration j runs
+// GEMM1(j), then GEMM2(j - 1) beside the GELU of chunk j -- so a wave's own VALU work also has MFMAs next to it.  A stage of the weight
+// stream holds W1(j) and W2'(j - 1); two stages.  Same arithmetic, same order of accumulation per output as the kernel above.
+template <int D, typename HT>
+__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
+  constexpr int FP = 2;
+  constexpr int KS1 = D / 32, FCH = D / 32, NCH = 4 * D / 32;      // FCH: output-channel fragments of ONE wave (half of d / 16)
+  constexpr int PW = FP * 16, P = 4 * PW;
+  constexpr int W1B = 32 * D * 2, W2B = D * 64, STAGE = W1B + W2B;
+  constexpr int NDMA = STAGE / 1024, DPW = NDMA / 8;
+  static_assert(NDMA % 8 == 0 && W1B % 1024 == 0, "whole wave-instructions per wave");
+  constexpr int XCH_OFF = 2 * STAGE, XCH_BYTES = 2 * 4 * 2 * FP * 64 * 8;                    // [parity][pair][half][block][lane] x 8 B
+  constexpr int AFF_OFF = XCH_OFF + XCH_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* aff = reinterpret_cast<float*>(smem + AFF_OFF);           // [D] b2'
+  float* b1s = aff + D;                                            // [4D] b1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 1, hh = wave & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int pbase = blockIdx.x * P + g * PW;
+  for (int c = tid; c < D; c += 512) aff[c] = p.ep.shift[c];
+  for (int c = tid; c < 4 * D; c += 512) b1s[c] = p.b1[c];
+
+  const srd_t w1srd = make_srd(p.w1), w2srd = make_srd(p.w2p);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned voff[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int inst = i * 8 + wave;
+    const int c = inst * 64 + lane;
+    if (inst * 1024 < W1B) {
+      const int slab = c / 128, r = (c % 128) / 4, sl = (c % 4) ^ swz4(r);
+      voff[i] = (unsigned)(r * D * 2 + slab * 64 + sl * 16);
+    } else {
+      const int c2 = c - W1B / 16;
+      const int r = c2 / 4, sl = (c2 % 4) ^ swz4(r);
+      voff[i] = (unsigned)(r * 4 * D * 2 + sl * 16);
+    }
+  }
+  auto stage = [&](int j, int buf) {     // stage j = W1 of chunk j (j < NCH) and W2' of chunk j - 1 (j >= 1)
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int inst = i * 8 + wave;
+      const unsigned dst = lds0 + buf * STAGE + inst * 1024;
+      if (inst * 1024 < W1B) { if (j < NCH) lds_dma16(w1srd, voff[i], j * 32 * D * 2, dst); }
+      else { if (j >= 1) lds_dma16(w2srd, voff[i], (j - 1) * 64, dst); }
+    }
+  };
+
+  uint4 tf[FP][KS1];
+  f32x4 acc2[FCH][FP];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const int pix = pbase + f * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      tf[f][ks] = pix < p.M ? *reinterpret_cast<const uint4*>(p.t + (long)pix * D + ks * 32 + lq * 8) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < FCH; ++i) {
+      uint2 r = uint2{0u, 0u};
+      if (p.res && pix < p.M) r = *reinterpret_cast<const uint2*>(p.res + (long)pix * D + (hh * FCH + i) * 16 + lq * 4);
+      acc2[i][f] = unpack4<HT>(r);
+    }
+  }
+  int a1off[KS1];
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) a1off[ks] = ks * 2048 + hh * 1024 + lr * 64 + ((lq ^ swz4(lr)) << 4);      // W1 rows 16 hh + lr
+  const int a2off = W1B + (hh * FCH * 16 + lr) * 64 + ((lq ^ swz4(lr)) << 4);                                   // W2' rows hh * d/2 + i * 16 + lr
+  uint2* const xch = reinterpret_cast<uint2*>(smem + XCH_OFF);
+  const int xmine = ((g * 2 + hh) * FP) * 64 + lane, xpeer = ((g * 2 + (1 - hh)) * FP) * 64 + lane;            // + parity * 4 * 2 * FP * 64 + f * 64
+
+  uint2 mine[FP];
+#pragma unroll
+  for (int f = 0; f < FP; ++f) mine[f] = uint2{0u, 0u};
+  stage(0, 0);
+#pragma unroll 1
+  for (int j0 = 0; j0 <= NCH; j0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {      // unrolled by the two LDS stages / exchange parities: offsets are immediates
+      const int j = j0 + u;
+      if (j > NCH) break;
+      wait_vm<0>();                    // my pieces of stage j have landed
+      lds_barrier();                   // everyone's have; the halves written in iteration j - 1 are visible; the other stage is free
+      if (j + 1 <= NCH && !MLP_ABL(p, 8)) stage(j + 1, (u + 1) & 1);
+      const char* st = smem + u * STAGE;
+      uint4 hb[FP];
+      if (j >= 1) {                    // GEMM2's B fragment of chunk j - 1: .xy from the pair's wave 0, .zw from its wave 1
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+          const uint2 peer = xch[((u + 1) & 1) * (4 * 2 * FP * 64) + xpeer + f * 64];
+          hb[f] = hh == 0 ? uint4{mine[f].x, mine[f].y, peer.x, peer.y} : uint4{peer.x, peer.y, mine[f].x, mine[f].y};
+        }
+      }
+      f32x4 h[FP];
+      if (j < NCH) {                   // GEMM1: this wave's 16 hidden rows of chunk j
+#pragma unroll
+        for (int f = 0; f < FP; ++f) h[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!MLP_ABL(p, 4))
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const uint4 w = *reinterpret_cast<const uint4*>(st + a1off[ks]);
+#pragma unroll
+          for (int f = 0; f < FP; ++f) h[f] = mfma_16x16x32<HT>(w, tf[f][ks], h[f]);
+        }
+      }
+      if (j >= 1 && !MLP_ABL(p, 2)) {  // GEMM2 of chunk j - 1 over this wave's half of the output channels ...
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) {
+          const uint4 w2 = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
+#pragma unroll
+          for (int f = 0; f < FP; ++f) acc2[i][f] = mfma_16x16x32<HT>(w2, hb[f], acc2[i][f]);
+        }
+      }
+      if (j < NCH) {                   // ... beside the bias + GELU + packing of chunk j's hidden units (independent of GEMM2)
+        const float4 bv = *reinterpret_cast<const float4*>(b1s + j * 32 + hh * 16 + lq * 4);
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+          f32x2_t a01 = f32x2_t{h[f][0] + bv.x, h[f][1] + bv.y}, a23 = f32x2_t{h[f][2] + bv.z, h[f][3] + bv.w};
+          if (!MLP_ABL(p, 1)) { a01 = gelu_poly2(a01); a23 = gelu_poly2(a23); }
+          mine[f] = uint2{pk2<HT>(a01.x, a01.y), pk2<HT>(a23.x, a23.y)};
+          xch[u * (4 * 2 * FP * 64) + xmine + f * 64] = mine[f];
+        }
+      }
+    }
+  }
+  HT* const yb = reinterpret_cast<HT*>(p.ep.y);
+#pragma unroll
+  for (int i = 0; i < FCH; ++i) {
+    const float4 sh = *reinterpret_cast<const float4*>(aff + (hh * FCH + i) * 16 + lq * 4);
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+      const int pix = pbase + f * 16 + lr;
+      if (pix >= p.M) continue;
+      uint2 o;
+      o.x = pk2<HT>(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
+      o.y = pk2<HT>(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
+      *reinterpret_cast<uint2*>(yb + (long)pix * D + (hh * FCH + i) * 16 + lq * 4) = o;
+    }
+  }
+}
+
+template <int D, typename HT>
+int launch_mlp_pair(const MlpP& p, hipStream_t s) {
+  constexpr int P = 4 * 2 * 16;
+  constexpr int STAGE = 32 * D * 2 + D * 64;
+  constexpr int lds = 2 * STAGE + 2 * 4 * 2 * 2 * 64 * 8 + 5 * D * 4;
+  static_assert(lds <= 160 * 1024, "LDS");
+  const long blocks = ((long)p.M + P - 1) / P;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
+  if (int rc = mtbt_allow_lds(mlp_pair_kernel<D, HT>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_pair_kernel<D, HT>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // d = 96: the WEIGHT-RESIDENT form.  W1 and W2' are 4 * 96 * 96 * 2 B * 2 = 147 KB: they fit the CU's 160 KB of LDS, so ONE persistent
 // workgroup per CU stages them once (all twelve chunks, the stage layout above) and its 16 waves (4 per SIMD) then run FREE: every wave
 // walks its own list of 32-pixel blocks -- load the block's fc1 inputs and residual, the twelve-chunk loop on the resident weights,
@@ -536,8 +701,11 @@ static int mlp_entry(const void* t, const void* res, const void* w1, const float
   // the one-off 147 KB weight stage per CU); small calls (tests, tiny maps) keep the streaming kernel
   if (D == 96 && M >= 64 * 1024 && M * 96 < 0x7fffffffL && MTBT_MLP_RESIDENT)
     return dtype == MTBT_F16 ? launch_mlp_resident<96, f16_t, 8, true>(p, s) : launch_mlp_resident<96, bf16_t, 8, true>(p, s);
-  if (dtype == MTBT_F16) return D == 96 ? launch_mlp<96, 2, 4, f16_t>(p, s) : (D == 192 ? launch_mlp<192, 2, 2, f16_t>(p, s) : launch_mlp<384, 2, 1, f16_t>(p, s));
-  return D == 96 ? launch_mlp<96, 2, 4, bf16_t>(p, s) : (D == 192 ? launch_mlp<192, 2, 2, bf16_t>(p, s) : launch_mlp<384, 2, 1, bf16_t>(p, s));
+  // round 3 (tools/mlp_variants.py, bit-identical outputs): d = 384 in the pair form 96 us against 122; d = 192 with the pipelined chunk
+  // 95 against 101 (the pair form there: 131 -- at d = 192 two waves per SIMD already fit without it and the exchange is pure overhead)
+  if (D == 384) return dtype == MTBT_F16 ? launch_mlp_pair<384, f16_t>(p, s) : launch_mlp_pair<384, bf16_t>(p, s);
+  if (D == 192) return dtype == MTBT_F16 ? launch_mlp<192, 2, 2, f16_t, true>(p, s) : launch_mlp<192, 2, 2, bf16_t, true>(p, s);
+  return dtype == MTBT_F16 ? launch_mlp<96, 2, 4, f16_t>(p, s) : launch_mlp<96, 2, 4, bf16_t>(p, s);
 }
 
 extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
