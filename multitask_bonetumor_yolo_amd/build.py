@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libmtbt_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_n.hip", "conv_direct_bf16.hip", "conv_igemm_f32.hip", "conv_igemm_f32_n.hip", "conv_direct_f32.hip", "conv_igemm_f16.hip", "conv_igemm_f16_n.hip", "conv_direct_f16.hip", "dwconv.hip", "dwconv_bf16.hip", "dwconv_f16.hip", "dwconv_f32.hip", "pointwise.hip", "postprocess.hip", "mask_mfma.hip", "bn_train.hip", "mlp_fused.hip", "upconv_fused.hip", "node_gemm.hip", "loss.hip", "preprocess.hip", "metrics.hip", "optim.hip", "wgrad.hip", "pointwise_bwd.hip", "train_ops.hip", "resample_bwd.hip"]
+SOURCES = ["conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_n.hip", "conv_direct_bf16.hip", "conv_igemm_f32.hip", "conv_igemm_f32_n.hip", "conv_direct_f32.hip", "conv_igemm_f16.hip", "conv_igemm_f16_n.hip", "conv_direct_f16.hip", "dwconv.hip", "dwconv_bf16.hip", "dwconv_f16.hip", "dwconv_f32.hip", "pointwise.hip", "postprocess.hip", "mask_mfma.hip", "bn_train.hip", "mlp_fused.hip", "upconv_fused.hip", "node_gemm.hip", "pw_stream.hip", "loss.hip", "preprocess.hip", "metrics.hip", "optim.hip", "wgrad.hip", "pointwise_bwd.hip", "train_ops.hip", "resample_bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-fno-gpu-rdc", "-Wno-unused-value"]

@@ -350,7 +350,7 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
 // 8 waves per workgroup = TWO per SIMD (<= 256 registers each), and inside a wave the loop is skewed by one chunk -- iteration j runs
 // GEMM1(j), then GEMM2(j - 1) beside the GELU of chunk j -- so a wave's own VALU work also has MFMAs next to it.  A stage of the weight
 // stream holds W1(j) and W2'(j - 1); two stages.  Same arithmetic, same order of accumulation per output as the kernel above.
-template <int D, typename HT>
+template <int D, typename HT, bool ORD = false>
 __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
   constexpr int FP = 2;
   constexpr int KS1 = D / 32, FCH = D / 32, NCH = 4 * D / 32;      // FCH: output-channel fragments of ONE wave (half of d / 16)
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
     const int pix = pbase + f * 16 + lr;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks)
-      tf[f][ks] = pix < p.M ? *reinterpret_cast<const uint4*>(p.t + (long)pix * D + ks * 32 + lq * 8) : uint4{0u, 0u, 0u, 0u};
+      tf[f][ks] = (pix < p.M && !MLP_ABL(p, 64)) ? *reinterpret_cast<const uint4*>(p.t + (long)pix * D + ks * 32 + lq * 8) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < FCH; ++i) {
       uint2 r = uint2{0u, 0u};
@@ -419,6 +419,21 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
   uint2* const xch = reinterpret_cast<uint2*>(smem + XCH_OFF);
   const int xmine = ((g * 2 + hh) * FP) * 64 + lane, xpeer = ((g * 2 + (1 - hh)) * FP) * 64 + lane;            // + parity * 4 * 2 * FP * 64 + f * 64
 
+  // GEMM2 of one chunk over this wave's half of the output channels
+  auto gemm2 = [&](const char* st, const uint4 (&hb)[FP]) {
+    if (MLP_ABL(p, 2)) return;
+#pragma unroll
+    for (int i = 0; i < FCH; ++i) {
+      const uint4 w2 = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
+#pragma unroll
+      for (int f = 0; f < FP; ++f) acc2[i][f] = mfma_16x16x32<HT>(w2, hb[f], acc2[i][f]);
+    }
+  };
+  // Waves w and w + 4 share a SIMD and, started together behind the same barrier, would run the same phase at the same time: both in
+  // MFMAs (the pipe is shared anyway), then both in GELU / exchange / barrier wait (the pipe idles).  The second half of the workgroup
+  // therefore runs the iteration in the other order -- GEMM2(j - 1), GEMM1(j), GELU -- so that one wave's VALU tail has the other's
+  // MFMAs beside it.  Same operations on the same data: the order inside an iteration is free (everything crosses iterations at the barrier).
+  const bool ord = ORD && (wave & 4);
   uint2 mine[FP];
 #pragma unroll
   for (int f = 0; f < FP; ++f) mine[f] = uint2{0u, 0u};
@@ -442,6 +457,8 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
         }
       }
       f32x4 h[FP];
+      const bool g2_first = ord && j >= 1;      // see `ord` above
+      if (g2_first) gemm2(st, hb);
       if (j < NCH) {                   // GEMM1: this wave's 16 hidden rows of chunk j
 #pragma unroll
         for (int f = 0; f < FP; ++f) h[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -453,14 +470,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
           for (int f = 0; f < FP; ++f) h[f] = mfma_16x16x32<HT>(w, tf[f][ks], h[f]);
         }
       }
-      if (j >= 1 && !MLP_ABL(p, 2)) {  // GEMM2 of chunk j - 1 over this wave's half of the output channels ...
-#pragma unroll
-        for (int i = 0; i < FCH; ++i) {
-          const uint4 w2 = *reinterpret_cast<const uint4*>(st + a2off + i * 1024);
-#pragma unroll
-          for (int f = 0; f < FP; ++f) acc2[i][f] = mfma_16x16x32<HT>(w2, hb[f], acc2[i][f]);
-        }
-      }
+      if (j >= 1 && !g2_first) gemm2(st, hb);      // GEMM2 of chunk j - 1 beside the GELU below (independent of it)
       if (j < NCH) {                   // ... beside the bias + GELU + packing of chunk j's hidden units (independent of GEMM2)
         const float4 bv = *reinterpret_cast<const float4*>(b1s + j * 32 + hh * 16 + lq * 4);
 #pragma unroll
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
       const int pix = pbase + f * 16 + lr;
-      if (pix >= p.M) continue;
+      if (pix >= p.M || MLP_ABL(p, 32)) continue;
       uint2 o;
       o.x = pk2<HT>(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
       o.y = pk2<HT>(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
   }
 }
 
-template <int D, typename HT>
+template <int D, typename HT, bool ORD = false>
 int launch_mlp_pair(const MlpP& p, hipStream_t s) {
   constexpr int P = 4 * 2 * 16;
   constexpr int STAGE = 32 * D * 2 + D * 64;
@@ -497,8 +507,8 @@ int launch_mlp_pair(const MlpP& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   const long blocks = ((long)p.M + P - 1) / P;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  if (int rc = mtbt_allow_lds(mlp_pair_kernel<D, HT>, lds)) return rc;
-  hipLaunchKernelGGL((mlp_pair_kernel<D, HT>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+  if (int rc = mtbt_allow_lds(mlp_pair_kernel<D, HT, ORD>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_pair_kernel<D, HT, ORD>), dim3((unsigned)blocks), dim3(512), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

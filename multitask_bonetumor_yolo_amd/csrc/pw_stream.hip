@@ -1,0 +1,126 @@
+// Output 1x1 convolutions of the Detect / Segment heads (ultralytics `Detect.cv2[i][2]`, `cv3[i][2]`, `Segment.cv4[i][2]`:
+// nn.Conv2d(64 | 256, 4 * reg_max | nc | nm, 1) with a bias, no activation -- main_model.py:300-340) as a STREAMING kernel.
+//
+//   y[p][k] = sum_c W[k][c] * x[p][c] + bias[k],       C in {32, 64, 128, 256},  K <= 64,  y fp32 with its own pixel / batch stride
+//
+// These 15 launches per forward move 13 MB in and 0.8 .. 26 MB out at P3 and far less on P4 / P5; through the implicit-GEMM kernel they cost
+// 7 .. 31 us each (LDS staging, barriers and a slab epilogue for a reduction of ONE or TWO MFMA steps: 0.11 of the HBM roof, round-2
+// verdict item 5 ii).  Nothing here needs LDS: a lane's 16-byte piece of a pixel row IS its MFMA B fragment, a lane's 16-byte piece of a
+// weight row IS its A fragment (the whole matrix is <= 16 KB: every wave keeps it in registers), and the accumulator layout -- 4
+// consecutive output channels of one pixel per lane -- stores as one 16-byte fp32 piece.  A wave owns 32 pixels; no barrier, no LDS.
+// The reduction runs in the same order as the implicit-GEMM kernel's (ascending 32-channel steps of v_mfma_f32_16x16x32) and the
+// bias is added the same way, so the result is bit-identical to that path.
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+template <typename T, int NST, int FC>
+__global__ __launch_bounds__(256) void pw_stream_kernel(const ConvP p) {
+  constexpr int FP = 2, C = NST * 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const long pix0 = ((long)blockIdx.x * 4 + wave) * (FP * 16);
+  if (pix0 >= p.M) return;
+  const int HW = p.H * p.W;
+  const T* const xb = reinterpret_cast<const T*>(p.x);
+  const T* const wb = reinterpret_cast<const T*>(p.w);
+
+  uint4 b[NST][FP];
+  long yoff[FP];
+  bool ok[FP];
+#pragma unroll
+  for (int j = 0; j < FP; ++j) {
+    const long pix = pix0 + j * 16 + lr;
+    ok[j] = pix < p.M;
+    const long pc = ok[j] ? pix : (long)p.M - 1;
+    const long n = pc / HW, r = pc - n * HW;
+    const T* xp = xb + n * p.xbs + r * p.ldx + lq * 8;
+    yoff[j] = n * p.ybs + r * p.ldy;
+#pragma unroll
+    for (int g = 0; g < NST; ++g) b[g][j] = *reinterpret_cast<const uint4*>(xp + g * 32);
+  }
+  uint4 a[NST][FC];
+#pragma unroll
+  for (int i = 0; i < FC; ++i) {
+    const int row = i * 16 + lr;
+#pragma unroll
+    for (int g = 0; g < NST; ++g)
+      a[g][i] = row < p.K ? *reinterpret_cast<const uint4*>(wb + (long)row * C + g * 32 + lq * 8) : uint4{0u, 0u, 0u, 0u};
+  }
+  f32x4 acc[FC][FP];
+#pragma unroll
+  for (int i = 0; i < FC; ++i)
+#pragma unroll
+    for (int j = 0; j < FP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < NST; ++g)
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+      for (int j = 0; j < FP; ++j) acc[i][j] = mfma_16x16x32<T>(a[g][i], b[g][j], acc[i][j]);
+
+  float* const yb = reinterpret_cast<float*>(p.y);
+#pragma unroll
+  for (int i = 0; i < FC; ++i) {
+    const int ch = i * 16 + lq * 4;
+    if (ch >= p.K) continue;
+    float sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[e] = (p.shift && ch + e < p.K) ? p.shift[ch + e] : 0.f;
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+      if (!ok[j]) continue;
+      float* yp = yb + yoff[j] + ch;
+      const float4 v = float4{acc[i][j][0] + sh[0], acc[i][j][1] + sh[1], acc[i][j][2] + sh[2], acc[i][j][3] + sh[3]};
+      if (p.vec_ok && ch + 4 <= p.K) *reinterpret_cast<float4*>(yp) = v;
+      else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ch + e < p.K) yp[e] = vv[e];
+      }
+    }
+  }
+}
+
+template <typename T, int NST>
+int launch_nst(const ConvP& p, hipStream_t s) {
+  const long blocks = ((long)p.M + 127) / 128;
+  if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
+  const int fc = (p.K + 15) / 16;
+  switch (fc) {
+    case 1: hipLaunchKernelGGL((pw_stream_kernel<T, NST, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((pw_stream_kernel<T, NST, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((pw_stream_kernel<T, NST, 3>), dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((pw_stream_kernel<T, NST, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p); break;
+    default: return MTBT_EINVAL;
+  }
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+template <typename T>
+int launch_t(const ConvP& p, hipStream_t s) {
+  switch (p.C / 32) {
+    case 1: return launch_nst<T, 1>(p, s);
+    case 2: return launch_nst<T, 2>(p, s);
+    case 4: return launch_nst<T, 4>(p, s);
+    case 8: return launch_nst<T, 8>(p, s);
+    default: return MTBT_EINVAL;
+  }
+}
+
+}  // namespace
+
+// Whether mtbt_conv2d_nhwc hands this call to the streaming kernel (conv_igemm.hip asks before it picks a tile).  `vec_ok` of p = 16-byte
+// fp32 stores are whole and aligned (pixel / batch stride multiples of 4 elements, aligned base): set by the caller.
+bool mtbt_pw_stream_applies(const ConvP& p, int dtype) {
+  return (dtype == MTBT_BF16 || dtype == MTBT_F16) && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && (p.C == 32 || p.C == 64 || p.C == 128 || p.C == 256) && p.K <= 64 &&
+         p.out_f32 && p.out_mode == MTBT_OUT_NHWC && p.act == MTBT_ACT_NONE && !p.scale && !p.res && !p.y2 && !p.cs_part && !p.debug;
+}
+
+int mtbt_pw_stream(const ConvP& p, int dtype, hipStream_t s) {
+  return dtype == MTBT_F16 ? launch_t<f16_t>(p, s) : launch_t<bf16_t>(p, s);
+}

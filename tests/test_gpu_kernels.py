@@ -128,6 +128,42 @@ def test_conv_channel_slices_and_f32_out(dtype):
     assert (out[:, 2:66] - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [
+    # (N, H, W, C, K, pitch of the fp32 map, channel offset in it, per-image rows of the map (> H*W: a pyramid level inside a larger buffer))
+    (2, 10, 10, 64, 64, 68, 0, 100),      # Detect cv2[i][2]: 4 * reg_max box channels of the [N,h,w,68] map
+    (2, 10, 10, 64, 2, 68, 64, 100),      # Detect cv3[i][2]: nc = 2 class channels behind them (scalar stores)
+    (3, 7, 9, 64, 32, 32, 0, 84),         # Segment cv4[i][2]: mask coefficients of one level inside [N, A, 32]; ragged last wave
+    (1, 5, 5, 128, 48, 48, 0, 25),        # four reduction steps, three channel fragments
+    (2, 6, 6, 256, 2, 68, 64, 36),        # the class conv behind a 256-channel branch
+    (1, 1, 1, 32, 16, 16, 0, 1),          # one pixel, one step
+])
+def test_head_output_conv_streams(dtype, cfg):
+    """main_model.py:300-340 (ultralytics Detect.cv2 / cv3 / Segment.cv4 `[i][2]`: Conv2d(c, k, 1) with bias): mtbt_conv2d_nhwc hands these
+    to pw_stream_kernel (no LDS).  Equal BIT FOR BIT to the implicit-GEMM kernel on the same call (a tile hint keeps it there), within
+    bf16 / fp16 operand rounding of torch's conv, and nothing outside the slice is written."""
+    N, H, W, Cin, K, pitch, c0, rows = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = (torch.randn(N, Cin, H, W, generator=g)).to(dtype).float()
+    w = (torch.randn(K, Cin, 1, 1, generator=g) / Cin ** 0.5).to(dtype).float()
+    b = torch.randn(K, generator=g)
+    ref = F.conv2d(x, w, b)
+    outs = []
+    for hint in (0, (64 << 16) | 64):
+        ybuf = torch.full((N, rows, pitch), 7.0, dtype=torch.float32, device=DEV)
+        ya = Act(ybuf, c0, N, H, W, K, pitch, rows * pitch)
+        p = Plan(torch.device(DEV))
+        p.conv(Act.of(nhwc(x).to(dtype)), w.reshape(K, Cin).contiguous().to(DEV, dtype), ya, R=1, S=1, shift=b.to(DEV), tile_hint=hint)
+        run(p)
+        outs.append(ybuf.clone())
+    assert torch.equal(outs[0], outs[1])
+    y = outs[0][:, :H * W, c0:c0 + K].reshape(N, H, W, K).permute(0, 3, 1, 2).cpu()
+    assert (y - ref).abs().max().item() < 1e-3          # fp32 accumulation of exactly representable products
+    mask = torch.ones_like(outs[0], dtype=torch.bool)
+    mask[:, :H * W, c0:c0 + K] = False
+    assert torch.all(outs[0][mask] == 7.0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_transpose_2x2(dtype):
     g = torch.Generator().manual_seed(4)

@@ -22,6 +22,7 @@ extern "C" int mlp_variant(int dbg, const void* t, const void* res, const void* 
   if (D == 96 && (dbg & 0x300) == 0x200) return launch_mlp_resident<96, bf16_t, 12>(p, s);
   if (D == 96 && (dbg & 0x300) == 0x300) return launch_mlp_resident<96, bf16_t, 8>(p, s);
   if (D == 96) return launch_mlp<96, 2, 4, bf16_t>(p, s);
+  if (D == 384 && (dbg & 0x2000)) return launch_mlp_pair<384, bf16_t, true>(p, s);
   if (D == 384 && (dbg & 0x1000)) return launch_mlp_pair<384, bf16_t>(p, s);
   if (D == 192 && (dbg & 0x1000)) return launch_mlp_pair<192, bf16_t>(p, s);
   if (D == 192 && (dbg & 0x800)) return launch_mlp<192, 2, 2, bf16_t, true>(p, s);
