@@ -136,7 +136,9 @@ def train_main(args, world, rank, dev):
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
             if name.endswith("_train_traffic.json") and (B, S, args.dtype) == (32, 640, "bf16"):
                 with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic_fam = {k: (round(v["traffic_bytes_per_launch"]), "profiles/" + name) for k, v in json.load(f).get("families", {}).items()}
+                    # HBM-side bytes per STEP of each family (rocprofv3 counts kernel dispatches, a plan launch may be several): divided
+                    # below by the plan's launches so that `traffic` and `algorithmic_bytes_per_launch` share a denominator
+                    traffic_fam = {k: (v["traffic_bytes_per_launch"] * v["launches_per_step"], "profiles/" + name) for k, v in json.load(f).get("families", {}).items()}
                 break
         peak_t = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
         roofline_families = {}
@@ -145,8 +147,8 @@ def train_main(args, world, rank, dev):
             ach = (fl / (t_ * 1e-3) / 1e12) if mfma else (by / (t_ * 1e-3) / 1e9)
             roofline_families[k] = {"bound": "mfma" if mfma else "hbm", "launches_per_step": n_, "ms_per_step": round(t_, 3), "achieved": round(ach, 1),
                                     "peak": peak_t if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / (peak_t if mfma else 8000.0), 4),
-                                    "algorithmic_bytes_per_launch": round(by / n_) if not mfma else None,
-                                    "traffic": traffic_fam.get(k, (None, None))[0], "traffic_source": traffic_fam.get(k, (None, None))[1]}
+                                    "algorithmic_bytes_per_launch": round(by / n_),
+                                    "traffic": round(traffic_fam[k][0] / n_) if k in traffic_fam else None, "traffic_source": traffic_fam.get(k, (None, None))[1]}
         flop_per_img = 545e9 * (S / 640.0) ** 2        # ~3x the 181.8 GFLOP forward
         ms_step = elapsed / args.steps * 1e3
         line = {"metric": "images/sec, training step (fwd + multitask loss + bwd + clip + optimizer) at 640x640", "value": round(world * B * args.steps / elapsed, 2),

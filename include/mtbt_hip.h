@@ -498,9 +498,10 @@ int mtbt_bn_forward_sums_nhwc(const void* x, void* y, int32_t y_pixel_stride, co
                               float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, const float* sums,
                               const float* shift, float* stats, void* stream);
 
-/* ... and straight from the conv's partial rows (second level and statistics in one launch). */
+/* ... and straight from the conv's partial rows (second level and statistics in one launch).  The partial rows are CONSUMED: a tall
+ * matrix (> 768 rows) is folded in place before the per-channel second level. */
 int mtbt_bn_forward_partials_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
-                                  float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, const float* partial,
+                                  float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype, float* partial,
                                   int64_t rows, int32_t pitch, const float* shift, float* stats, void* stream);
 
 /* Backward of activation + BatchNorm2d in one operator: dy = gradient of the ACTIVATED output (rows of dy_pixel_stride elements),

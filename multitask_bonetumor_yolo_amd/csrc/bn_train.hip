@@ -5,10 +5,9 @@
 //
 // Deterministic statistics: per-workgroup (mean, M2) partials in a workspace, combined exactly in a fixed order; no atomics.
 #include "common.h"
+#include "rowreduce.h"
 
 namespace {
-
-constexpr int ROWS_PER_BLOCK = 256;
 
 // ---- single-pass statistics: every workgroup reduces its ROWS_PER_BLOCK rows to a per-channel (mean_b, M2_b)
 // with sums SHIFTED by the block's first row (no cancellation for |mean| >> sigma); the final kernel combines the blocks exactly
@@ -264,7 +263,7 @@ extern "C" int mtbt_bn_forward_sums_nhwc(const void* x, void* y, int32_t y_pixel
 // ... and from the conv's partial rows (mtbt_conv_colsum_layout gives rows / pitch): no separate second level.
 extern "C" int mtbt_bn_forward_partials_nhwc(const void* x, void* y, int32_t y_pixel_stride, const float* gamma, const float* beta, float* running_mean,
                                              float* running_var, float momentum, float eps, int act, int64_t pixels, int C, int dtype,
-                                             const float* partial, int64_t rows, int32_t pitch, const float* shift, float* stats, void* stream) {
+                                             float* partial, int64_t rows, int32_t pitch, const float* shift, float* stats, void* stream) {
   if (!x || !y || !gamma || !beta || !stats || !partial || rows <= 0 || rows > 0x7fffffffL || pitch < 2 * C || pixels <= 0 || C <= 0 || C % 8 || C > 2048 ||
       y_pixel_stride < C || y_pixel_stride % 8)
     return MTBT_EINVAL;
@@ -276,11 +275,11 @@ extern "C" int mtbt_bn_forward_partials_nhwc(const void* x, void* y, int32_t y_p
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* mean = stats;
   float* var = stats + C;
-  hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, (int)rows, pitch, shift, (long)pixels, C, mean, var,
+  long rr = rows;
+  int pp = pitch;
+  colsum_prereduce(partial, rr, pp, 0, 2 * C, s);      // tall matrices: folded in place first (rowreduce.h)
+  hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, partial, (int)rr, pp, shift, (long)pixels, C, mean, var,
                      running_mean, running_var, momentum);
-  const long total = pixels * CH8;
-  long g = (total + 255) / 256;
-  if (g > 8192) g = 8192;
   if (dtype == MTBT_F32) launch_bn_apply<float>(x, y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride, s);
   else launch_bn_apply<bf16_t>(x, y, mean, var, gamma, beta, eps, act, (long)pixels, C, y_pixel_stride, s);
   MTBT_LAUNCH_CHECK();

@@ -87,9 +87,11 @@ extern "C" int64_t mtbt_conv_colsum_workspace_bytes(int64_t pixels, int K, int w
 // second level of the column sums: `rows` partial rows -> colsum (one wave per channel, fixed order)
 static int colsum_finish(const mtbt_conv_args* a, const ConvP& p, long rows, hipStream_t s) {
   if (rows <= 0 || rows > 0x7fffffffL) return MTBT_EINVAL;
-  hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((a->K + 3) / 4)), dim3(256), 0, s, p.cs_part, (int)rows, p.cs_pitch, 0, a->K, a->colsum, a->colsum_accumulate);
+  int pitch = p.cs_pitch;
+  colsum_prereduce(p.cs_part, rows, pitch, 0, p.cs_pitch, s);       // (tall matrices: in place, see rowreduce.h)
+  hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((a->K + 3) / 4)), dim3(256), 0, s, p.cs_part, (int)rows, pitch, 0, a->K, a->colsum, a->colsum_accumulate);
   if (a->colsum_sq)
-    hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((a->K + 3) / 4)), dim3(256), 0, s, p.cs_part, (int)rows, p.cs_pitch, a->K, a->K, a->colsum + a->K, a->colsum_accumulate);
+    hipLaunchKernelGGL(channel_sum_final_pitch, dim3((unsigned)((a->K + 3) / 4)), dim3(256), 0, s, p.cs_part, (int)rows, pitch, a->K, a->K, a->colsum + a->K, a->colsum_accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

@@ -65,6 +65,51 @@ __global__ __launch_bounds__(256) void channel_sum_final(const float* __restrict
   if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
+// Pre-reduction of a TALL partial matrix, in place.  The one-wave-per-column second levels read a column with one 4-byte access per row:
+// every access is its own 64-byte sector, which 15 other waves fetch again -- at the 3 200 .. 51 200 partial rows the conv epilogues write
+// for the 80^2 / 160^2 maps of a batch-32 step that is 16x the matrix in L2 traffic and 200+ dependent trips per lane (round 3: the second
+// levels took 12 - 15 us on average, 3.3 ms per step together).  Here a workgroup is 16 row lanes x 16 columns (a wave reads four whole
+// sectors per instruction), owns `per` consecutive rows and leaves their column sums in ITS OWN first row -- the only row of the matrix it
+// may overwrite without a reader still waiting for it.  The caller then runs the second level over S rows of pitch per * pitch.
+__global__ __launch_bounds__(256) void colsum_tile_kernel(float* __restrict__ partial, int rows, int pitch, int c0, int cols, int per) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (c < cols) {
+    const float* col = partial + c0 + c;
+    int r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {
+      const float v0 = col[(long)r * pitch], v1 = col[(long)(r + 16) * pitch], v2 = col[(long)(r + 32) * pitch], v3 = col[(long)(r + 48) * pitch];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; r < r1; r += 16) s += col[(long)r * pitch];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    partial[(long)r0 * pitch + c0 + c] = t;
+  }
+}
+
+// host side: reduce `partial` ([rows][pitch], columns [c0, c0 + cols)) in place when it is tall; returns the (rows, pitch) the second level
+// is to use.  Deterministic (fixed segment boundaries and orders).
+static inline void colsum_prereduce(float* partial, long& rows, int& pitch, int c0, int cols, hipStream_t s) {
+  if (rows <= 768 || rows > 0x7fffffffL) return;
+  long S = (rows + 255) / 256;
+  if (S > 48) S = 48;
+  const long per = (rows + S - 1) / S;
+  S = (rows + per - 1) / per;
+  if (per * pitch > 0x7fffffffL) return;
+  hipLaunchKernelGGL(colsum_tile_kernel, dim3((unsigned)((cols + 15) / 16), (unsigned)S), dim3(256), 0, s, partial, (int)rows, pitch, c0, cols, (int)per);
+  rows = S;
+  pitch = (int)(per * pitch);
+}
+
 // the same over a [blocks][pitch] partial matrix, columns [c0, c0 + C)
 __global__ __launch_bounds__(256) void channel_sum_final_pitch(const float* __restrict__ partial, int blocks, int pitch, int c0, int C, float* __restrict__ out,
                                                                int accumulate) {

@@ -139,12 +139,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ dy, 
 }
 
 // one wave per column of the [blocks][2C] partials: sums[0..C) = s1 = d beta, sums[C..2C) = s2 = d gamma
-__global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ partial, int blocks, int C, float* __restrict__ sums,
+__global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ partial, int blocks, int pitch, int C, float* __restrict__ sums,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= 2 * C) return;
   float s = 0.f;
-  for (int b = lane; b < blocks; b += 64) s += partial[(long)b * 2 * C + c];
+  for (int b = lane; b < blocks; b += 64) s += partial[(long)b * pitch + c];
   s = wave_sum(s);
   if (lane == 0) {
     sums[c] = s;
@@ -478,7 +478,8 @@ extern "C" int mtbt_bn_backward_nhwc(const void* dy, int32_t dy_pixel_stride, co
 #define BNB2(T, A, F)                                                                                                                      \
   hipLaunchKernelGGL((bn_bwd_partial<T, A>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy, dy_pixel_stride, (const T*)x, (long)pixels, C, mean, var, \
                      gamma, beta, eps, act, partial);                                                                                      \
-  hipLaunchKernelGGL(bn_bwd_final, dim3((unsigned)((2 * C + 3) / 4)), dim3(256), 0, s, partial, (int)blocks, C, sums, dgamma, dbeta, accumulate);     \
+  { long rr = blocks; int pp = 2 * C; colsum_prereduce(partial, rr, pp, 0, 2 * C, s);                                                      \
+    hipLaunchKernelGGL(bn_bwd_final, dim3((unsigned)((2 * C + 3) / 4)), dim3(256), 0, s, partial, (int)rr, pp, C, sums, dgamma, dbeta, accumulate); }  \
   hipLaunchKernelGGL((bn_bwd_apply<T, A, F>), dim3(ga), dim3(256), 0, s, (const T*)dy, dy_pixel_stride, (const T*)x, (T*)dx, (long)pixels, C, mean, var, gamma, \
                      beta, eps, act, sums, use_running);
 #define BNB(T)                                                                        \
