@@ -95,27 +95,50 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
   f32p acc[KS * KS], accb = f32p{0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < KS * KS; ++t) acc[t] = f32p{0.f, 0.f};
-  for (long tl = slot; tl < ntiles; tl += nslots) {
+  // Staging through REGISTERS, one tile ahead: all of a thread's 16-byte pieces of tile t + 1 (13 of the halo + 4 of dy for 7 x 7 bf16) are
+  // requested before the FMAs of tile t and written to LDS behind them.  (Round 3: the first version loaded and stored piece by piece in
+  // one loop -- every piece waited for its own round trip, 12 dependent latencies per tile: 24 us per tile where the FMAs need 1.3, 610 us
+  // for a stage-0 launch that moves 315 MB.)
+  constexpr int NHX = (IW * IW * PARTS + 255) / 256, NDY = (TS * TS * PARTS + 255) / 256;
+  uint4 hx[NHX], hd[NDY];
+  auto fetch = [&](long tl) {
     const int tx = (int)(tl % tiles_x), ty = (int)((tl / tiles_x) % tiles_y), n = (int)(tl / ((long)tiles_x * tiles_y));
     const int y0 = ty * TS, x0 = tx * TS;
-    __syncthreads();                                       // the previous tile's readers are done
-    for (int it = tid; it < IW * IW * PARTS; it += 256) {   // halo: zeros outside the image / past the chunk's channels
+#pragma unroll
+    for (int k = 0; k < NHX; ++k) {                         // halo: zeros outside the image / past the chunk's channels
+      const int it = tid + k * 256;
       const int pix = it / PARTS, part = it - pix * PARTS;
       const int r = pix / IW, c = pix - r * IW;
       const int iy = y0 + r - PAD, ix = x0 + c - PAD;
-      uint4 v = uint4{0u, 0u, 0u, 0u};
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && part * EPC < cc)
-        v = *reinterpret_cast<const uint4*>(x + (((long)n * H + iy) * W + ix) * C + cb + part * EPC);
-      *reinterpret_cast<uint4*>(xt + pix * PIXB + part * 16) = v;
+      hx[k] = uint4{0u, 0u, 0u, 0u};
+      if (it < IW * IW * PARTS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && part * EPC < cc)
+        hx[k] = *reinterpret_cast<const uint4*>(x + (((long)n * H + iy) * W + ix) * C + cb + part * EPC);
     }
-    for (int it = tid; it < TS * TS * PARTS; it += 256) {
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int it = tid + k * 256;
       const int pix = it / PARTS, part = it - pix * PARTS;
       const int oy = y0 + pix / TS, ox = x0 + pix % TS;
-      uint4 v = uint4{0u, 0u, 0u, 0u};
-      if (oy < H && ox < W && part * EPC < cc) v = *reinterpret_cast<const uint4*>(dy + (((long)n * H + oy) * W + ox) * C + cb + part * EPC);
-      *reinterpret_cast<uint4*>(dt + pix * PIXB + part * 16) = v;
+      hd[k] = uint4{0u, 0u, 0u, 0u};
+      if (it < TS * TS * PARTS && oy < H && ox < W && part * EPC < cc)
+        hd[k] = *reinterpret_cast<const uint4*>(dy + (((long)n * H + oy) * W + ox) * C + cb + part * EPC);
+    }
+  };
+  if (slot < ntiles) fetch(slot);
+  for (long tl = slot; tl < ntiles; tl += nslots) {
+    __syncthreads();                                       // the previous tile's readers are done
+#pragma unroll
+    for (int k = 0; k < NHX; ++k) {
+      const int it = tid + k * 256;
+      if (it < IW * IW * PARTS) *reinterpret_cast<uint4*>(xt + (it / PARTS) * PIXB + (it % PARTS) * 16) = hx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int it = tid + k * 256;
+      if (it < TS * TS * PARTS) *reinterpret_cast<uint4*>(dt + (it / PARTS) * PIXB + (it % PARTS) * 16) = hd[k];
     }
     __syncthreads();
+    if (tl + nslots < ntiles) fetch(tl + nslots);          // in flight during this tile's FMAs
     if (active) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {

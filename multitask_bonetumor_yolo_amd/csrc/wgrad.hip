@@ -403,26 +403,62 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
-    __syncthreads();
-    for (int it = tid; it < 64 * 12; it += 192) {
+  // Staging through registers, one step ahead (round 3: the first version loaded and stored piece by piece, the rows of d ELEMENT by element --
+  // 32 dependent trips of 2-byte loads per step: 528 us for a launch that moves 315 MB): a thread's four image pieces and its 16-byte
+  // pieces of d for step t + 1 are requested before the FMAs of step t.
+  constexpr int EPC = 16 / (int)sizeof(T), ND = (64 * (128 / EPC) + 191) / 192;
+  const int dparts = K / EPC;                              // 16-byte pieces per row of d (K % 8 == 0)
+  float4 vi[4];
+  uint4 vd[ND];
+  auto fetch = [&](long base) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = tid + u * 192;
       const int pix = it % 64, cky = it / 64;
       const long gp = base + pix;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gp < total) {
         const int n = (int)(gp / (Ho * Wo));
         const int rem = (int)(gp - (long)n * Ho * Wo);
         const int oy = rem / Wo, ox = rem - oy * Wo;
-        v = *reinterpret_cast<const float4*>(img + (((long)n * 3 + (cky >> 2)) * H + (oy * 4 + (cky & 3))) * W + ox * 4);
+        vi[u] = *reinterpret_cast<const float4*>(img + (((long)n * 3 + (cky >> 2)) * H + (oy * 4 + (cky & 3))) * W + ox * 4);
       }
-      *reinterpret_cast<float4*>(patch + pix * 48 + cky * 4) = v;
     }
-    for (int it = tid; it < 64 * K; it += 192) {
-      const int pix = it / K, k = it - pix * K;
-      const long gp = base + pix;
-      dk[pix * K + k] = gp < total ? ld_elem<T>(d + gp * K + k) : 0.f;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int it = tid + u * 192;
+      const int pix = it / dparts, part = it - pix * dparts;
+      vd[u] = uint4{0u, 0u, 0u, 0u};
+      if (it < 64 * dparts && base + pix < total) vd[u] = *reinterpret_cast<const uint4*>(d + (base + pix) * K + part * EPC);
+    }
+  };
+  const long bstep = (long)gridDim.x * 64;
+  if ((long)blockIdx.x * 64 < total) fetch((long)blockIdx.x * 64);
+  for (long base = (long)blockIdx.x * 64; base < total; base += bstep) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = tid + u * 192;
+      *reinterpret_cast<float4*>(patch + (it % 64) * 48 + (it / 64) * 4) = vi[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int it = tid + u * 192;
+      if (it < 64 * dparts) {
+        float f[EPC];
+        if constexpr (sizeof(T) == 4) { f[0] = __uint_as_float(vd[u].x); f[1] = __uint_as_float(vd[u].y); f[2] = __uint_as_float(vd[u].z); f[3] = __uint_as_float(vd[u].w); }
+        else {
+          const uint32_t w4[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w4[e] << 16); f[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+        }
+        float* dst = dk + (it / dparts) * K + (it % dparts) * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+      }
     }
     __syncthreads();
+    if (base + bstep < total) fetch(base + bstep);
     if (own) {
       for (int pix = 0; pix < 64; ++pix) {   // 3 x 16-byte LDS reads for 32 FMAs
         const float4 pv = *reinterpret_cast<const float4*>(patch + pix * 48 + cg * 4);
@@ -567,7 +603,7 @@ extern "C" int mtbt_stem_wgrad(const float* x, const void* d, float* dw, int N, 
                                int64_t workspace_bytes, void* stream) {
   if (!x || !d || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || K <= 0 || K % 8 || K > 128) return MTBT_EINVAL;
   if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
-  if (!aligned16(x) || !aligned16(workspace)) return MTBT_EALIGN;
+  if (!aligned16(x) || !aligned16(d) || !aligned16(workspace)) return MTBT_EALIGN;
   if (workspace_bytes < mtbt_stem_wgrad_workspace_bytes(K)) return MTBT_EWORKSPACE;
   const long total = (long)N * (H / 4) * (W / 4);
   long blocks = (total + 63) / 64;
