@@ -328,7 +328,7 @@ def main():
         # by tools/summarize_pmc.py with the guide's gfx950 corrections; bench.py cannot run the profiler on itself
         traffic, traffic_src, traffic_all = None, None, None
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            if name.endswith("_traffic.json") and args.dtype == "bf16" and (B, IMG) == (BATCH_PER_GPU, 640):
+            if name.endswith("_traffic.json") and not name.endswith("_train_traffic.json") and args.dtype == "bf16" and (B, IMG) == (BATCH_PER_GPU, 640):
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
                 traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/" + name

@@ -47,6 +47,7 @@ extern "C" {
 #define MTBT_ACT_DGELU 7 /* e.g. the ConvNeXt fc2 input gradient lands directly as d(fc1 pre-activation) */
 #define MTBT_ACT_GELU_POLY 4 /* the same GELU as x * Phi(x) with Phi an odd degree-13 polynomial on [-4,4]: |error| <= 2.3e-4,
                               below bf16 resolution; no exp / rcp.  For bf16 outputs (the fp32 parity mode uses MTBT_ACT_GELU). */
+#define MTBT_ACT_DGELU_POLY 8 /* backward epilogue for MTBT_ACT_GELU_POLY: the EXACT derivative of that polynomial form (no erf / exp) */
 
 /* conv output addressing */
 #define MTBT_OUT_NHWC 0

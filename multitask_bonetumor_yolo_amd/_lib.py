@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
 
 ABI_VERSION = 3          # include/mtbt_hip.h MTBT_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY, ACT_DSILU, ACT_DELU, ACT_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
+ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY, ACT_DSILU, ACT_DELU, ACT_DGELU, ACT_DGELU_POLY = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OUT_NHWC, OUT_CONVT2X2 = 0, 1
 RES_ID, RES_UP_BILINEAR, RES_DOWN_MEAN, RES_UP_NEAREST, RES_MAXPOOL = 0, 1, 2, 3, 4
 

@@ -135,6 +135,23 @@ __device__ __forceinline__ float gelu_poly(float x) {
   return x * fmaf(xc, p, 0.5f);
 }
 
+// d/dx of gelu_poly: g(x) = x / 2 + x^2 P(x^2) on |x| < 4  ->  g'(x) = 1/2 + 2 x Q(x^2), Q(s) = P(s) + s P'(s) (coefficients (i + 1) c_i);
+// outside, xc is constant and g is linear: g' = 1/2 + xc P(16).  The exact derivative of what the forward computed; 8 plain VALU operations.
+__device__ __forceinline__ float gelu_poly_grad(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
+  const float s = xc * xc;
+  float q = fmaf(7.0f * 2.1609857e-08f, s, 6.0f * -1.5335673e-06f);
+  q = fmaf(q, s, 5.0f * 4.6542096e-05f);
+  q = fmaf(q, s, 4.0f * -7.9887325e-04f);
+  q = fmaf(q, s, 3.0f * 8.6900834e-03f);
+  q = fmaf(q, s, 2.0f * -6.4366050e-02f);
+  q = fmaf(q, s, 3.9770728e-01f);
+  constexpr float P16 = ((((((2.1609857e-08f * 16.f + -1.5335673e-06f) * 16.f + 4.6542096e-05f) * 16.f + -7.9887325e-04f) * 16.f + 8.6900834e-03f) * 16.f +
+                          -6.4366050e-02f) * 16.f + 3.9770728e-01f);
+  const float inside = fmaf(2.0f * xc, q, 0.5f), outside = fmaf(xc, P16, 0.5f);
+  return fabsf(x) < 4.0f ? inside : outside;
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case MTBT_ACT_SILU: return v * fast_rcp(1.0f + fast_exp(-v));
@@ -150,7 +167,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == MTBT_ACT_SILU || act == MTBT_ACT_DSILU) { const float s = fast_rcp(1.f + fast_exp(-z)); return s * (1.f + z * (1.f - s)); }
   if (act == MTBT_ACT_ELU || act == MTBT_ACT_DELU) return z > 0.f ? 1.f : fast_exp(z);
-  if (act == MTBT_ACT_GELU || act == MTBT_ACT_GELU_POLY || act == MTBT_ACT_DGELU)
+  if (act == MTBT_ACT_GELU_POLY || act == MTBT_ACT_DGELU_POLY) return gelu_poly_grad(z);
+  if (act == MTBT_ACT_GELU || act == MTBT_ACT_DGELU)
     return 0.5f * (1.f + fast_erf(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * fast_exp(-0.5f * z * z);
   return 1.f;
 }

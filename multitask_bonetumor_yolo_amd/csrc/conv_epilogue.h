@@ -281,7 +281,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
   if constexpr (sizeof(T) == 2) {
   if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
     if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
-    if (TRAIN && p.act == MTBT_ACT_DGELU) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU, 2, true>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    // (16-bit storage: the polynomial derivative has the compiled body; MTBT_ACT_DGELU falls through to the general one)
+    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
   } else if (fast && !(TRAIN && p.y2)) {
     switch (p.act) {
       case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;
@@ -291,7 +292,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
       case MTBT_ACT_GELU_POLY: MTBT_FAST(MTBT_ACT_GELU_POLY, 0); return;
       case MTBT_ACT_DSILU: if (TRAIN) { MTBT_FAST(MTBT_ACT_DSILU, 2); return; } break;
       case MTBT_ACT_DELU: if (TRAIN) { MTBT_FAST(MTBT_ACT_DELU, 2); return; } break;
-      case MTBT_ACT_DGELU: if (TRAIN) { MTBT_FAST(MTBT_ACT_DGELU, 2); return; } break;
+      case MTBT_ACT_DGELU_POLY: if (TRAIN) { MTBT_FAST(MTBT_ACT_DGELU_POLY, 2); return; } break;
       default: break;
     }
   } else if (TRAIN && fast) {   // second output = the pre-activation (training forward of fc1)

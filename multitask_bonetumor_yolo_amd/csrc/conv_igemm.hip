@@ -109,7 +109,7 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
   if (a->Ho != (a->H + 2 * a->pad - a->R) / a->stride + 1 || a->Wo != (a->W + 2 * a->pad - a->S) / a->stride + 1) return MTBT_EINVAL;
   if (a->out_mode != MTBT_OUT_NHWC && a->out_mode != MTBT_OUT_CONVT2X2) return MTBT_EINVAL;
   if (a->out_mode == MTBT_OUT_CONVT2X2 && (a->K % 4 != 0)) return MTBT_EINVAL;
-  if (a->act < 0 || a->act > MTBT_ACT_DGELU) return MTBT_EINVAL;
+  if (a->act < 0 || a->act > MTBT_ACT_DGELU_POLY) return MTBT_EINVAL;
   if (a->act >= MTBT_ACT_DSILU && !a->res) return MTBT_EINVAL;  // the derivative epilogues read the pre-activation through res
   if (a->y2 && (a->out_mode != MTBT_OUT_NHWC || !aligned16(a->y2))) return MTBT_EINVAL;
   if (!aligned16(a->x) || !aligned16(a->w) || a->x_pixel_stride % epc != 0 || a->x_batch_stride % epc != 0) return MTBT_EALIGN;

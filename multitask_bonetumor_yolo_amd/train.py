@@ -726,7 +726,11 @@ class TrainPlan:
         y = self.new(N, H, W, d)
         self.fwd.dwconv_t(cur, taps, t, 7, bias=blk.conv_dw.bias, lnw=blk.norm.weight, lnb=blk.norm.bias, eps=blk.norm.eps, raw=r,
                           name=name + ".conv_dw+norm")
-        self.fwd.conv2(t, w1f, h, shift=fc1.bias, act=L.ACT_GELU, y2=hpre, name=name + ".mlp.fc1")
+        # bf16: GELU as x * Phi(x) with the polynomial Phi of the inference path (|error| <= 2.3e-4, below bf16 resolution) and, in the
+        # backward, the EXACT derivative of that polynomial -- no erf / exp in either epilogue (round 3: the erf forms made the epilogues
+        # of fc1 and of fc2-dgrad VALU-bound at stage 2); the fp32 parity mode keeps the erf forms
+        poly = T != L.F32
+        self.fwd.conv2(t, w1f, h, shift=fc1.bias, act=L.ACT_GELU_POLY if poly else L.ACT_GELU, y2=hpre, name=name + ".mlp.fc1")
         self.fwd.conv(h, w2f, y, scale=gamma, shift=shift2, res=cur, name=name + ".mlp.fc2")
         gtmp = torch.empty(d, 4 * d, dtype=torch.float32, device=self.device)
         ssum = torch.empty(d, dtype=torch.float32, device=self.device)
@@ -747,7 +751,7 @@ class TrainPlan:
             d_hpre = self.bwd.new(N, H, W, 4 * d, T)
             # (d fc1.bias = sum_p d_hpre comes out of the same launch: column sums in the epilogue instead of a pass over the 4d-wide tensor)
             fused_db = self.bwd.colsum_ok(4 * d) and FUSED_BN_STATS
-            self.bwd.conv2(dy, w2d, d_hpre, act=L.ACT_DGELU, res=hpre, name=name + ".fc2.dgrad*gelu'", colsum=self.pg(fc1.bias).view(-1) if fused_db else None)
+            self.bwd.conv2(dy, w2d, d_hpre, act=L.ACT_DGELU_POLY if poly else L.ACT_DGELU, res=hpre, name=name + ".fc2.dgrad*gelu'", colsum=self.pg(fc1.bias).view(-1) if fused_db else None)
             self.bwd.wgrad(t, d_hpre, self.pg(fc1.weight), R=1, S=1, pad=0, name=name + ".fc1.wgrad")
             if not fused_db:
                 self.bwd.channel_sum(d_hpre, self.pg(fc1.bias), name=name + ".fc1.dbias")

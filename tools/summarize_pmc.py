@@ -9,13 +9,13 @@ Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both count
 is exact for 16-byte-per-lane stores.  Infinity-Cache hits are included (memory-side of L2), so this is an upper bound on HBM bytes."""
 import csv, glob, json, os, sys
 
-FAMILIES = {"conv": ("conv_igemm_kernel", "conv3x3_direct_kernel", "conv3x3_rr_kernel", "upconv_fused_kernel", "node_gemm_kernel"), "dwconv": ("dwconv_kernel",),
-            "mlp_fused": ("mlp_fused_kernel",), "bifpn_fuse": ("fuse_kernel",), "layernorm": ("layernorm_kernel",), "stem": ("stem_mfma_kernel", "stem_kernel"),
+FAMILIES = {"conv": ("conv_igemm_kernel", "conv3x3_direct_kernel", "conv3x3_rr_kernel", "upconv_fused_kernel", "node_gemm_kernel", "pw_stream_kernel"), "dwconv": ("dwconv_kernel",),
+            "mlp_fused": ("mlp_fused_kernel", "mlp_pair_kernel"), "bifpn_fuse": ("fuse_kernel",), "layernorm": ("layernorm_kernel",), "stem": ("stem_mfma_kernel", "stem_kernel"),
             "mask_assembly": ("mask_x4_kernel",)}
 if "--train" in sys.argv:      # families of the training step (bench.py --mode train): the names bench.py's roofline_families uses
     sys.argv.remove("--train")
-    FAMILIES = {"wgrad": ("wgrad_kernel", "wgrad_f32_kernel", "wgrad_reduce_kernel", "stem_wgrad_kernel", "wgrad3x3"), "conv_fwd_dgrad": ("conv_igemm_kernel", "conv3x3_rr_kernel", "conv3x3_direct_kernel"),
-                "batchnorm": ("bn_block_stats", "bn_combine_stats", "bn_apply", "bn_bwd_partial", "bn_bwd_final", "bn_bwd_apply", "bn_stats_from", "bn_copy_stats"),
+    FAMILIES = {"wgrad": ("wgrad_kernel", "wgrad_f32_kernel", "wgrad_reduce_kernel", "stem_wgrad_kernel", "wgrad3x3"), "conv_fwd_dgrad": ("conv_igemm_kernel", "conv3x3_rr_kernel", "conv3x3_direct_kernel", "pw_stream_kernel"),
+                "batchnorm": ("bn_block_stats", "bn_combine_stats", "bn_apply", "bn_bwd_partial", "bn_bwd_final", "bn_bwd_apply", "bn_stats_from", "bn_copy_stats", "colsum_tile"),
                 "depthwise": ("dwconv_kernel", "dw_wgrad"), "layernorm": ("layernorm_kernel", "layernorm_bwd"), "channel_sums": ("channel_sum",),
                 "weight_prep": ("weight_prep_kernel",)}
 
@@ -45,7 +45,7 @@ for k in FAMILIES:
     fb, wb = 2.0 * fk * 1024 / nf, wk * 1024 / nw
     fams[k] = {"dispatches_fetch_pass": nf, "dispatches_write_pass": nw, "launches_per_step": nf / execs, "fetch_bytes_per_launch": fb,
                "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb}
-out = {"kernel": "conv_igemm_kernel + conv3x3_direct_kernel + conv3x3_rr_kernel (all tiles)", "plan_executions": execs,
+out = {"kernel": "conv_igemm_kernel + conv3x3_rr_kernel + upconv_fused_kernel + node_gemm_kernel + pw_stream_kernel (all tiles)", "plan_executions": execs,
        "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE x1; KiB units; Infinity-Cache hits included",
        "families": fams}
 out.update({k: v for k, v in fams.get("conv", {}).items()})
