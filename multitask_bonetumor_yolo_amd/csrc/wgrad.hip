@@ -20,6 +20,12 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef MTBT_WGRAD_XCD_SLICES
+#define MTBT_WGRAD_XCD_SLICES 0
+#endif
+#ifndef MTBT_WGRAD_WIDE
+#define MTBT_WGRAD_WIDE 1
+#endif
 constexpr int TK = 128, TCH = 128, TPX = 64, LPT = TPX / 16;   // LPT: 16-byte loads per thread and tile in one step
 
 struct WgP {
@@ -44,14 +50,22 @@ __device__ __forceinline__ int tile_off(int row, int col) {   // element offset 
   return row * 128 + (swz_unit(row, col >> 4) << 4) + (col & 15);
 }
 
-template <bool BIAS>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t sdy[TPX * TK];
-  __shared__ __attribute__((aligned(16))) bf16_t sx[TPX * TCH];
-  // Workgroup -> (pixel slice, tap, tile).  All tiles of one slice read the SAME dY / X rows, so they are placed on ONE XCD (consecutive
-  // workgroup ids go round the 8 XCDs) and next to each other in dispatch order: the slice then reaches that XCD's L2 once instead of once
-  // per tile from the fabric (round 3 PMC: the family fetched 2.8x its algorithmic bytes; the stage-2 MLP gradients, 36 tiles per slice,
-  // 4.8x -- Infinity-Cache-bound at 360 TFLOP/s).
+// NK x NC: the tile is (128 NK output channels) x (128 NC input channels), each of the 2 x 2 waves 64 NK x 64 NC.  (1, 1) is the base
+// form.  The GEMM-shaped gradients of the ConvNeXt MLPs (K, C = 384 .. 3072 at 12 800 .. 204 800 pixels) are bound by operand traffic, not
+// MFMA time: a 128 x 128 tile does 64 FLOP per byte it stages and ran at 360 TFLOP/s = 5.6 TB/s out of L2 / Infinity Cache; (2, 1) / (1, 2)
+// stage 3/4 of the bytes for twice the MFMAs (85 FLOP/B) at the price of 128 accumulator registers.  The wide side is laid out as two
+// 128-column panels of the base LDS image.
+template <bool BIAS, int NK, int NC>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
+  constexpr int TKt = TK * NK, TCt = TCH * NC, FA = 4 * NK, FB = 4 * NC;
+  __shared__ __attribute__((aligned(16))) bf16_t sdy[TPX * TKt];
+  __shared__ __attribute__((aligned(16))) bf16_t sx[TPX * TCt];
+  // Workgroup -> (pixel slice, tap, tile).  xcd_slices (MTBT_WGRAD_XCD_SLICES, OFF): all tiles of one slice on ONE XCD (consecutive
+  // workgroup ids go round the 8 XCDs) so that the slice reaches that XCD's L2 once instead of once per tile from the fabric -- the family
+  // fetches 2.8x its algorithmic bytes (round-3 PMC; the stage-2 MLP gradients, 36 tiles per slice, 4.8x).  MEASURED SLOWER: the MLP weight
+  // gradients went 168 -> 220 us (stage 2) and 210 -> 305 us (stage 0), everything else unchanged -- 3 .. 36 workgroups that start together
+  // and walk the same rows in lockstep queue on the same L2 channels, where the spread mapping is served by eight L2s and the Infinity
+  // Cache in parallel.  The re-reads are cheap; the fix for these layers is a wider tile (fewer, larger operand passes), not placement.
   const int taps = p.R * p.S;
   int b = blockIdx.x, split;
   if (p.xcd_slices) {
@@ -68,39 +82,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
   const int tap = b;
   const int r = tap / p.S, s = tap - r * p.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave & 1, wc = wave >> 1;            // wave tile: 64 output channels x 64 input channels
-  const int row = tid >> 4, chunk = tid & 15;         // staging: tile row (pixel of the pass), 16-byte chunk (8 channels)
+  const int wk = wave & 1, wc = wave >> 1;            // wave tile: 64 NK output channels x 64 NC input channels
+  const int row = tid >> 4, chunk = tid & 15;         // staging: tile row (pixel of the pass), 16-byte chunk (8 channels) of a 128-column panel
   const int HW = p.Ho * p.Wo;                       // pixels are those of dY
   const long p0 = (long)split * p.per, p1 = min(p.P, p0 + p.per);
-  const int kch = kt * TK + chunk * 8, cch = ct * TCH + chunk * 8;
+  const int kch = kt * TKt + chunk * 8, cch = ct * TCt + chunk * 8;
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
 
-  f32x4 acc[4][4];
+  f32x4 acc[FA][FB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FA; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // bias gradient for free: the workgroups of (first input-channel tile, first tap) also multiply their dY fragments with a
   // fragment of ONES -- D[k][j] = sum_p dY[p][k] in every column j (4 extra MFMAs per 16, in 1 / (ctiles * taps) of the workgroups)
   const bool do_bias = BIAS && p.bpartial != nullptr && ct == 0 && tap == 0 && wc == 0;
-  f32x4 accb[4];
+  f32x4 accb[FA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < FA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
 
-  uint4 vdy[LPT], vx[LPT];
+  uint4 vdy[NK][LPT], vx[NC][LPT];
   auto fetch = [&](long pb) {   // this thread's 16-byte pieces of the step starting at pixel pb (zeros past the slice / outside the image)
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const long pix = pb + i * 16 + row;
-      vdy[i] = vx[i] = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int h = 0; h < NK; ++h) vdy[h][i] = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int h = 0; h < NC; ++h) vx[h][i] = uint4{0u, 0u, 0u, 0u};
       if (pix < p1) {
         const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
         const int y = rem / p.Wo, xx = rem - y * p.Wo;
-        if (kch < p.K) vdy[i] = *reinterpret_cast<const uint4*>(p.dy + (long)n * p.dy_bs + (long)rem * p.ldy + kch);
+        const bf16_t* dyp = p.dy + (long)n * p.dy_bs + (long)rem * p.ldy;
+#pragma unroll
+        for (int h = 0; h < NK; ++h)
+          if (kch + h * 128 < p.K) vdy[h][i] = *reinterpret_cast<const uint4*>(dyp + kch + h * 128);
         const int iy = y * p.stride + r - p.pad, ix = xx * p.stride + s - p.pad;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && cch < p.C)
-          vx[i] = *reinterpret_cast<const uint4*>(p.x + (long)n * p.x_bs + ((long)iy * p.W + ix) * p.ldx + cch);
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          const bf16_t* xp = p.x + (long)n * p.x_bs + ((long)iy * p.W + ix) * p.ldx;
+#pragma unroll
+          for (int h = 0; h < NC; ++h)
+            if (cch + h * 128 < p.C) vx[h][i] = *reinterpret_cast<const uint4*>(xp + cch + h * 128);
+        }
       }
     }
   };
@@ -110,8 +134,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
       const int tr = i * 16 + row;
-      *reinterpret_cast<uint4*>(sdy + tile_off(tr, chunk * 8)) = vdy[i];
-      *reinterpret_cast<uint4*>(sx + tile_off(tr, chunk * 8)) = vx[i];
+#pragma unroll
+      for (int h = 0; h < NK; ++h) *reinterpret_cast<uint4*>(sdy + h * (TPX * 128) + tile_off(tr, chunk * 8)) = vdy[h][i];
+#pragma unroll
+      for (int h = 0; h < NC; ++h) *reinterpret_cast<uint4*>(sx + h * (TPX * 128) + tile_off(tr, chunk * 8)) = vx[h][i];
     }
     __syncthreads();
     if (pb + TPX < p1) fetch(pb + TPX);                // the next step's global loads are in flight during this step's MFMAs
@@ -119,44 +145,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgP p) {
 #pragma unroll
     for (int i = 0; i < TPX / 32; ++i) {
       const int r_lo = i * 32 + 8 * g + q, r_hi = r_lo + 4;     // operand k index 8g .. 8g+3 and 8g+4 .. 8g+7 of this 32-pixel group
-      s16x8 A[4], B[4];
+      s16x8 B[FB];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const int ca = 64 * wk + 16 * f + 4 * pp, cb = 64 * wc + 16 * f + 4 * pp;
-        A[f] = __builtin_shufflevector(tr_read(sdy + tile_off(r_lo, ca)), tr_read(sdy + tile_off(r_hi, ca)), 0, 1, 2, 3, 4, 5, 6, 7);
-        B[f] = __builtin_shufflevector(tr_read(sx + tile_off(r_lo, cb)), tr_read(sx + tile_off(r_hi, cb)), 0, 1, 2, 3, 4, 5, 6, 7);
+      for (int f = 0; f < FB; ++f) {
+        const int cb = 64 * NC * wc + 16 * f + 4 * pp;          // column of the wave's c range: panel cb / 128
+        const bf16_t* base = sx + (cb >> 7) * (TPX * 128);
+        B[f] = __builtin_shufflevector(tr_read(base + tile_off(r_lo, cb & 127)), tr_read(base + tile_off(r_hi, cb & 127)), 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int fa = 0; fa < 4; ++fa)
+      for (int ha = 0; ha < NK; ++ha) {                         // the A fragments four at a time (16 registers live)
+        s16x8 A[4];
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb)
-          acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, B[fb]), acc[fa][fb], 0, 0, 0);
-      if (BIAS && do_bias) {   // (wave-uniform)
+        for (int f = 0; f < 4; ++f) {
+          const int ca = 64 * NK * wk + 16 * (ha * 4 + f) + 4 * pp;
+          const bf16_t* base = sdy + (ca >> 7) * (TPX * 128);
+          A[f] = __builtin_shufflevector(tr_read(base + tile_off(r_lo, ca & 127)), tr_read(base + tile_off(r_hi, ca & 127)), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 #pragma unroll
         for (int fa = 0; fa < 4; ++fa)
-          accb[fa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, ones), accb[fa], 0, 0, 0);
+#pragma unroll
+          for (int fb = 0; fb < FB; ++fb)
+            acc[ha * 4 + fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, B[fb]), acc[ha * 4 + fa][fb], 0, 0, 0);
+        if (BIAS && do_bias) {   // (wave-uniform)
+#pragma unroll
+          for (int fa = 0; fa < 4; ++fa)
+            accb[ha * 4 + fa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, ones), accb[ha * 4 + fa], 0, 0, 0);
+        }
       }
     }
   }
   if (BIAS && do_bias && (lane & 15) == 0) {
 #pragma unroll
-    for (int fa = 0; fa < 4; ++fa)
+    for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int k = kt * TK + 64 * wk + 16 * fa + 4 * (lane >> 4) + e;
+        const int k = kt * TKt + 64 * NK * wk + 16 * fa + 4 * (lane >> 4) + e;
         if (k < p.K) p.bpartial[(long)split * p.K + k] = accb[fa][e];
       }
   }
-  // lane: output channel kt*128 + 64 wk + 16 fa + 4 (lane / 16) + e, input channel ct*128 + 64 wc + 16 fb + lane % 16
+  // lane: output channel kt * TKt + 64 NK wk + 16 fa + 4 (lane / 16) + e, input channel ct * TCt + 64 NC wc + 16 fb + lane % 16
   const long RSC = (long)taps * p.C;
 #pragma unroll
-  for (int fa = 0; fa < 4; ++fa)
+  for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
-    for (int fb = 0; fb < 4; ++fb) {
-      const int c = ct * TCH + 64 * wc + 16 * fb + (lane & 15);
+    for (int fb = 0; fb < FB; ++fb) {
+      const int c = ct * TCt + 64 * NC * wc + 16 * fb + (lane & 15);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int k = kt * TK + 64 * wk + 16 * fa + 4 * (lane >> 4) + e;
+        const int k = kt * TKt + 64 * NK * wk + 16 * fa + 4 * (lane >> 4) + e;
         if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)tap * p.C + c] = acc[fa][fb][e];
       }
     }
@@ -500,11 +536,27 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
-int pick_split(int K, int C, int taps, long P) {
+// the tile of the generic kernel for a shape: wide on the side that is a multiple of 256 channels when the other side spans more than one
+// 128-channel tile too (only then is there an operand pass to save)
+// (not with the fused bias gradient: its extra accumulators spill at two waves per SIMD)
+static inline void pick_wide(int K, int C, bool allow, int* nk, int* nc) {
+  *nk = *nc = 1;
+#if MTBT_WGRAD_WIDE
+  if (allow && K > 128 && C > 128) {
+    if (K % 256 == 0 && K >= C) *nk = 2;
+    else if (C % 256 == 0) *nc = 2;
+    else if (K % 256 == 0) *nk = 2;
+  }
+#endif
+}
+
+int pick_split(int K, int C, int taps, long P, bool allow_wide) {
   // Slices are the only parallelism beyond the (few) output tiles, but every slice writes and re-reads a full fp32 copy of dW:
   // aim at ~6 workgroups per CU while a slice keeps >= 24 steps; accept shorter slices (>= 8 steps) only to reach 2 per CU.
   // (Measured on five of the network's shapes, tools/wgrad_probe.py; within ~15 % of the best split found for each.)
-  const long tiles = (long)((K + TK - 1) / TK) * ((C + TCH - 1) / TCH) * taps;
+  int nk, nc;
+  pick_wide(K, C, allow_wide, &nk, &nc);
+  const long tiles = (long)((K + TK * nk - 1) / (TK * nk)) * ((C + TCH * nc - 1) / (TCH * nc)) * taps;
   auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
 #ifndef MTBT_WGRAD_TARGET
 #define MTBT_WGRAD_TARGET 512    // workgroups aimed at (batch-32 shapes, tools/wgrad_ab.py: 1536 -> 1024 was 12 % less time: fewer fp32 partial copies of dW; 512 once the
@@ -523,7 +575,8 @@ int pick_split(int K, int C, int taps, long P) {
 extern "C" int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R, int S) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return 0;
   // an upper bound for every stride: slices never outnumber those of the stride-1 case (fewer dY pixels)
-  return (int64_t)pick_split(K, C, R * S, (long)N * H * W) * ((int64_t)K * R * S * C + K) * (int64_t)sizeof(float);
+  const int a = pick_split(K, C, R * S, (long)N * H * W, true), b = pick_split(K, C, R * S, (long)N * H * W, false);
+  return (int64_t)(a > b ? a : b) * ((int64_t)K * R * S * C + K) * (int64_t)sizeof(float);
 }
 
 static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
@@ -537,7 +590,7 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
   const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(workspace)) return MTBT_EALIGN;
   const long P = (long)N * Ho * Wo;
-  const int nsplit = pick_split(K, C, R * S, P);
+  const int nsplit = pick_split(K, C, R * S, P, dbias == nullptr);
   // the slices actually launched decide the workspace (a padding > (R-1)/2 makes Ho*Wo exceed H*W, beyond the documented bound)
   if (workspace_bytes < (int64_t)nsplit * ((int64_t)K * R * S * C + K) * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
   float* bpartial = dbias ? reinterpret_cast<float*>(workspace) + (int64_t)nsplit * K * R * S * C : nullptr;
@@ -575,7 +628,7 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
     if (ns < 1) ns = 1;
     q.nsplit = (int)ns;
     q.per = (q.ntiles + ns - 1) / ns;
-    q.xcd_slices = ns >= 8;
+    q.xcd_slices = MTBT_WGRAD_XCD_SLICES && ns >= 8;
     const long blocks3 = base * (q.xcd_slices ? (ns + 7) / 8 * 8 : ns);
     if (blocks3 > 0x7fffffffL) return MTBT_EINVAL;
     hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3((unsigned)blocks3), dim3(256), 0, st, q);
@@ -591,12 +644,20 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
   p.P = P;
   p.nsplit = nsplit;
   p.per = ((p.P + p.nsplit - 1) / p.nsplit + TPX - 1) / TPX * TPX;
-  p.ktiles = (K + TK - 1) / TK; p.ctiles = (C + TCH - 1) / TCH;
-  p.xcd_slices = p.nsplit >= 8;
+  int nk, nc;
+  pick_wide(K, C, dbias == nullptr, &nk, &nc);
+  p.ktiles = (K + TK * nk - 1) / (TK * nk); p.ctiles = (C + TCH * nc - 1) / (TCH * nc);
+  p.xcd_slices = MTBT_WGRAD_XCD_SLICES && p.nsplit >= 8;
   const long blocks = (long)(p.xcd_slices ? (p.nsplit + 7) / 8 * 8 : p.nsplit) * R * S * p.ktiles * p.ctiles;
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
-  if (dbias) hipLaunchKernelGGL(wgrad_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+#define WG(B_)                                                                                                       \
+  do {                                                                                                               \
+    if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);          \
+    else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, p);     \
+    else hipLaunchKernelGGL((wgrad_kernel<B_, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);                  \
+  } while (0)
+  if (dbias) WG(true); else WG(false);
+#undef WG
   launch_wgrad_reduce(p.partial, dw, n, p.nsplit, accumulate, st);
   if (dbias) launch_wgrad_reduce(bpartial, dbias, (long)K, p.nsplit, accumulate, st);
   MTBT_LAUNCH_CHECK();

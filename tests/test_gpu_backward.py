@@ -83,7 +83,11 @@ def test_dwconv_dgrad(dtype, C, k, H):
     check(dx.buf, want, dtype)
 
 
-@pytest.mark.parametrize("N,H,W,C,K,k", [(2, 16, 16, 64, 64, 3), (1, 20, 20, 128, 96, 3), (2, 9, 7, 96, 384, 1), (3, 40, 40, 256, 64, 3), (1, 5, 3, 8, 8, 3)])
+@pytest.mark.parametrize("N,H,W,C,K,k", [(2, 16, 16, 64, 64, 3), (1, 20, 20, 128, 96, 3), (2, 9, 7, 96, 384, 1), (3, 40, 40, 256, 64, 3), (1, 5, 3, 8, 8, 3),
+                                         (2, 9, 7, 384, 512, 1),      # wide tile on the output channels (256 x 128: K % 256 == 0, K >= C), ragged last pixel step
+                                         (2, 9, 7, 512, 384, 1),      # wide tile on the input channels (128 x 256)
+                                         (1, 12, 12, 256, 256, 1),    # square 256: one wide tile per row
+                                         (1, 6, 6, 256, 192, 3)])     # k x k taps with a wide input side, ragged output-channel tile
 def test_conv_wgrad(N, H, W, C, K, k):
     """Weight gradient (csrc/wgrad.hip) vs autograd, bf16-rounded operands, ragged channel tiles and pixel slices."""
     g = torch.Generator().manual_seed(N * H + K + k)
