@@ -122,7 +122,7 @@ def train_main(args, world, rank, dev):
                 for l, t in sorted(zip(plan.launches, ms), key=lambda p: -p[1])[:25]:
                     print(f"{tag} {t*1e3:9.1f} us  {l.flops/(t*1e-3)/1e12 if t > 0 else 0:7.1f} TF/s  {l.name}", file=sys.stderr)
         # ---- per-family roofline of the step's kernels (HIP events around every launch of the two plans, single stream) ----
-        fam_of = {"mtbt_conv_wgrad": "wgrad", "mtbt_conv_wgrad_bias": "wgrad", "mtbt_stem_wgrad": "wgrad", "mtbt_conv2d_nhwc": "conv_fwd_dgrad",
+        fam_of = {"mtbt_conv_wgrad": "wgrad", "mtbt_conv_wgrad_bias": "wgrad", "mtbt_conv_wgrad_xact": "wgrad", "mtbt_convnext_mlp_fused_train": "conv_fwd_dgrad", "mtbt_stem_wgrad": "wgrad", "mtbt_conv2d_nhwc": "conv_fwd_dgrad",
                   "mtbt_bn_forward_nhwc": "batchnorm", "mtbt_bn_forward_partials_nhwc": "batchnorm", "mtbt_bn_backward_nhwc": "batchnorm",
                   "mtbt_dwconv_nhwc_train": "depthwise", "mtbt_dwconv_wgrad": "depthwise", "mtbt_dwconv_wgrad_bias": "depthwise",
                   "mtbt_layernorm_nhwc": "layernorm", "mtbt_layernorm_backward_params_nhwc": "layernorm", "mtbt_channel_sum": "channel_sums",

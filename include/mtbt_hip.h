@@ -55,7 +55,7 @@ extern "C" {
 
 /* Bumped whenever an argument struct or a signature below changes (round 1 = 1; round 2 added fields / positional arguments without
  * bumping it; round 3 starts at 3).  The library travels prebuilt: a binding built against another header must refuse to load. */
-#define MTBT_ABI_VERSION 3
+#define MTBT_ABI_VERSION 4
 int mtbt_abi_version(void);
 /* sizeof() of the argument structs as the LIBRARY was compiled: which = 0 mtbt_conv_args, 1 mtbt_fuse_args, 2 mtbt_decode_args,
  * 3 mtbt_mask_args, 4 mtbt_loss_args, 5 mtbt_prep_desc, 6 mtbt_raw_image, 7 mtbt_upconv_args, 8 mtbt_node_args; -1 for any other value.  A binding compares them with its
@@ -359,6 +359,13 @@ int mtbt_convnext_mlp_fused(const void* t, const void* res, const void* w1, cons
 /* the same with the 16-bit storage type given: MTBT_BF16 or MTBT_F16 */
 int mtbt_convnext_mlp_fused_dt(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
                                const float* b2, void* y, int64_t M, int D, int dtype, void* stream);
+/* Training forward of the same block (bf16, d in {96, 192}): y as above PLUS hpre [M][4d] bf16 = W1 . t + b1, the fc1 PRE-activation in
+ * natural hidden order -- all the backward needs (GELU' in the fc2 input gradient, GELU re-applied by mtbt_conv_wgrad_xact); the activated
+ * hidden tensor is never written.  Weight order of THIS entry: w1_perm / b1_perm have their rows permuted inside every group of 32 hidden
+ * units -- row 16 b + 4 g + e holds hidden unit 8 g + 4 b + e (b = 0..1, g = 0..3, e = 0..3) -- and w2 [d][4d] keeps the natural column
+ * order (layer scale folded into its rows, b2 = gamma * fc2.bias).  Replaces timm Mlp.forward under model.train(), main_model.py:21-26. */
+int mtbt_convnext_mlp_fused_train(const void* t, const void* res, const void* w1_perm, const float* b1_perm, const void* w2, const float* b2,
+                                  void* y, void* hpre, int64_t M, int D, void* stream);
 
 /* Pairwise IoU of xyxy boxes (running_main_v3.py:71-97, `batch_bbox_iou`): out[i][j] = inter / (area1_i + area2_j - inter + eps),
  * inter = clamp(min(x2)-max(x1), 0) * clamp(min(y2)-max(y1), 0); fp32, the reference's operation order without FMA
@@ -401,6 +408,11 @@ int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int R
 int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
                     int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with an activation applied to x while it is staged (x_act = MTBT_ACT_GELU_POLY; bf16, 1 x 1): x is a kept PRE-activation,
+ * dw[k][c] (+)= sum_p dy[p][k] * gelu(x[p][c]) -- the fc2 weight gradient behind mtbt_convnext_mlp_fused_train. */
+int mtbt_conv_wgrad_xact(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
+                         int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
+                         int x_act, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same plus the bias gradient dbias[k] (+)= sum_p dy[p][k] (`Conv2d.bias.grad`, `Linear.bias.grad`, and the sum_p dy the layer-scale
  * gradient needs) from the dY fragments the kernel holds anyway: the workgroups of the first input-channel tile and tap multiply them
  * with a fragment of ones -- no separate pass over dy. */

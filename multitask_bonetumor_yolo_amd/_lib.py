@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
 
-ABI_VERSION = 3          # include/mtbt_hip.h MTBT_ABI_VERSION
+ABI_VERSION = 4          # include/mtbt_hip.h MTBT_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY, ACT_DSILU, ACT_DELU, ACT_DGELU, ACT_DGELU_POLY = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OUT_NHWC, OUT_CONVT2X2 = 0, 1
@@ -121,6 +121,7 @@ SYMBOLS = {
     "mtbt_multitask_loss_grad": (C.c_int, [C.POINTER(LossArgs), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtbt_convnext_mlp_fused": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_void_p]),
     "mtbt_convnext_mlp_fused_dt": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mtbt_convnext_mlp_fused_train": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int, C.c_void_p]),
     "mtbt_bbox_iou_pairwise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mtbt_letterbox_batch": (C.c_int, [C.POINTER(RawImage), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "mtbt_seg_confusion_workspace_bytes": (C.c_int64, [C.c_int]),
@@ -128,6 +129,8 @@ SYMBOLS = {
     "mtbt_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 7),
     "mtbt_conv_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
+    "mtbt_conv_wgrad_xact": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 9 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_int64, C.c_void_p]),
     "mtbt_conv_wgrad_bias": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int, C.c_int, C.c_void_p,
                                        C.c_int64, C.c_void_p]),
     "mtbt_act_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),

@@ -69,6 +69,7 @@ struct MlpP {
   const float* b1;     // [4D]
   const bf16_t* w2p;   // [D][4D], hidden order permuted per 32-chunk (see top)
   const bf16_t* res;   // [M][D] residual (may be NULL)
+  bf16_t* hpre;        // HP kernels (training): [M][4D] fc1 PRE-activation, written in natural hidden order -- see mtbt_convnext_mlp_fused_train
   int M;
   int dbg;             // development ablation bits (MTBT_MLP_DEBUG): 1 = no GELU, 2 = no GEMM2, 4 = no GEMM1, 8 = no weight DMA
   ConvP ep;            // epilogue view: shift = b2', res, y, K = D
@@ -89,7 +90,7 @@ template <> __device__ __forceinline__ f32x4 unpack4<f16_t>(uint2 r) { return f3
 // scheduling region), the GELU of block 1, GEMM2 of both.  The unpipelined order is GEMM1 -> GELU -> GEMM2 with nothing beside the
 // GELU's ~130 VALU instructions, and at one wave per SIMD (d = 384) no other wave fills that hole (ISA of round 2: 96 MFMAs, then 260
 // VALU, then 96 MFMAs per chunk).  The chunk's W1 fragments stay in registers for both blocks (one LDS read per two MFMAs as before).
-template <int D, int FP, int WPS, typename HT, bool PIPE = false>
+template <int D, int FP, int WPS, typename HT, bool PIPE = false, bool HP = false>
 __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   constexpr int KS1 = D / 32;            // k-steps of GEMM1
   constexpr int FC = D / 16;             // output-channel fragments of GEMM2
@@ -175,6 +176,11 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   for (int ks = 0; ks < KS1; ++ks) a1off[ks] = ks * 2048 + lr * 64 + ((lq ^ swz4(lr)) << 4);   // + blk * 16 rows * 64
   a2off = W1B + lr * 64 + ((lq ^ swz4(lr)) << 4);                                              // + i * 16 rows * 64
 
+  unsigned hpoff[HP ? FP : 1];            // HP: byte offset of (pixel, hidden 8 lq) in hpre (address = scalar chunk base + this; M * 8 D < 2^32)
+  if constexpr (HP) {
+#pragma unroll
+    for (int f = 0; f < FP; ++f) hpoff[f] = (unsigned)(pbase + f * 16 + lr) * (unsigned)(8 * D) + (unsigned)(lq * 16);
+  }
   stage(0, 0);
   stage(1, 1);
 #pragma unroll 1
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
     for (int u = 0; u < NBUF; ++u) {  // unrolled by the LDS stages: buffer offsets are immediates
       const int jj = j + u;
       // this wave's pieces of chunk jj have landed (the next chunk's may still be in flight; the tf loads are older)
-      if (jj + 1 < NCH) wait_vm<DPW>(); else wait_vm<0>();
+      // (HP: the previous chunk's FP pre-activation stores are younger than that DMA and count in vmcnt too)
+      if (jj + 1 < NCH) wait_vm<DPW + (HP ? FP : 0)>(); else wait_vm<0>();
       lds_barrier();                  // everyone's have, and everyone is done reading the buffer restaged next
       if (jj + 2 < NCH && !(p.dbg & 8)) stage(jj + 2, (u + 2) % NBUF);
       const char* st = smem + u * STAGE;
@@ -193,8 +200,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
       if constexpr (PIPE) {
         static_assert(FP == 2, "two pixel blocks per wave");
         // a lane's 4 hidden units of one 16-row block -> bias + GELU -> two packed pairs (half of GEMM2's B fragment)
-        auto gelu_half = [&](const f32x4& hv, const float4& bv, uint32_t& lo, uint32_t& hi) {
+        uint4 hp0, hp1;                 // HP: the packed PRE-activations of the lane's 4 + 4 hidden units (one 16-byte store per pixel block)
+        auto gelu_half = [&](const f32x4& hv, const float4& bv, uint32_t& lo, uint32_t& hi, uint32_t& plo, uint32_t& phi) {
           f32x2_t a01 = f32x2_t{hv[0] + bv.x, hv[1] + bv.y}, a23 = f32x2_t{hv[2] + bv.z, hv[3] + bv.w};
+          if constexpr (HP) { plo = pk2<HT>(a01.x, a01.y); phi = pk2<HT>(a23.x, a23.y); }
           a01 = gelu_poly2(a01); a23 = gelu_poly2(a23);
           lo = pk2<HT>(a01.x, a01.y); hi = pk2<HT>(a23.x, a23.y);
         };
@@ -226,8 +235,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
             h0b = mfma_16x16x32<HT>(wb[ks], tf[0][ks], h0b);
             h1b = mfma_16x16x32<HT>(wb[ks], tf[1][ks], h1b);
           }
-          gelu_half(h0a, ba, hb0.x, hb0.y);
-          gelu_half(h1a, ba, hb1.x, hb1.y);
+          gelu_half(h0a, ba, hb0.x, hb0.y, hp0.x, hp0.y);
+          gelu_half(h1a, ba, hb1.x, hb1.y, hp1.x, hp1.y);
           // schedule of the region: all fragment reads first, a few GELU instructions while they fly, then one MFMA and up to three VALU
           // instructions, 2 * KS1 times (the GELU rides in the issue slots the MFMAs leave: ~66 VALU for 24 MFMAs)
           __builtin_amdgcn_sched_group_barrier(0x100, KS1, 0);
@@ -241,8 +250,12 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
         __builtin_amdgcn_sched_barrier(0);
         // region 3: GELU of the "b" rows (nothing to put beside it inside this chunk), then GEMM2 of both blocks: one weight fragment, two
         // MFMAs, the fragments requested PD steps ahead (left to itself hipcc reads a fragment, waits, issues its two MFMAs)
-        gelu_half(h0b, bb, hb0.z, hb0.w);
-        gelu_half(h1b, bb, hb1.z, hb1.w);
+        gelu_half(h0b, bb, hb0.z, hb0.w, hp0.z, hp0.w);
+        gelu_half(h1b, bb, hb1.z, hb1.w, hp1.z, hp1.w);
+        if constexpr (HP) {
+          if (pbase + lr < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.hpre) + (size_t)(jj * 64) + (size_t)hpoff[0]) = hp0;
+          if (pbase + 16 + lr < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.hpre) + (size_t)(jj * 64) + (size_t)hpoff[1]) = hp1;
+        }
         constexpr int PD = 4;
         uint4 w2q[PD];
 #pragma unroll
@@ -285,6 +298,11 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
       for (int f = 0; f < FP; ++f) {
         f32x2_t a01 = f32x2_t{h[0][f][0] + ba.x, h[0][f][1] + ba.y}, a23 = f32x2_t{h[0][f][2] + ba.z, h[0][f][3] + ba.w};
         f32x2_t c01 = f32x2_t{h[1][f][0] + bb.x, h[1][f][1] + bb.y}, c23 = f32x2_t{h[1][f][2] + bb.z, h[1][f][3] + bb.w};
+        if constexpr (HP) {             // the pre-activation of the lane's 8 CONSECUTIVE hidden units (training weight order): one 16-byte store
+          if (pbase + f * 16 + lr < p.M)
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.hpre) + (size_t)(jj * 64) + (size_t)hpoff[f]) =
+                uint4{pk2<HT>(a01.x, a01.y), pk2<HT>(a23.x, a23.y), pk2<HT>(c01.x, c01.y), pk2<HT>(c23.x, c23.y)};
+        }
         if (!(p.dbg & 1)) { a01 = gelu_poly2(a01); a23 = gelu_poly2(a23); c01 = gelu_poly2(c01); c23 = gelu_poly2(c23); }   // packed fp32 pairs
         hb[f].x = pk2<HT>(a01.x, a01.y); hb[f].y = pk2<HT>(a23.x, a23.y);
         hb[f].z = pk2<HT>(c01.x, c01.y); hb[f].w = pk2<HT>(c23.x, c23.y);
@@ -323,7 +341,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   }
 }
 
-template <int D, int FP, int WPS, typename HT, bool PIPE = false>
+template <int D, int FP, int WPS, typename HT, bool PIPE = false, bool HP = false>
 int launch_mlp(const MlpP& p, hipStream_t s) {
   constexpr int P = 4 * FP * 16;
   constexpr int STAGE = 32 * D * 2 + D * 64;
@@ -331,8 +349,8 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   const long blocks = ((long)p.M + P - 1) / P;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS, HT, PIPE>, lds)) return rc;
-  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS, HT, PIPE>), dim3((unsigned)blocks), dim3(256), lds, s, p);
+  if (int rc = mtbt_allow_lds(mlp_fused_kernel<D, FP, WPS, HT, PIPE, HP>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_fused_kernel<D, FP, WPS, HT, PIPE, HP>), dim3((unsigned)blocks), dim3(256), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -350,7 +368,7 @@ int launch_mlp(const MlpP& p, hipStream_t s) {
 // 8 waves per workgroup = TWO per SIMD (<= 256 registers each), and inside a wave the loop is skewed by one chunk -- iteration j runs
 // GEMM1(j), then GEMM2(j - 1) beside the GELU of chunk j -- so a wave's own VALU work also has MFMAs next to it.  A stage of the weight
 // stream holds W1(j) and W2'(j - 1); two stages.  Same arithmetic, same order of accumulation per output as the kernel above.
-template <int D, typename HT, bool ORD = false>
+template <int D, typename HT, bool ORD = false, bool HP = false>
 __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
   constexpr int FP = 2;
   constexpr int KS1 = D / 32, FCH = D / 32, NCH = 4 * D / 32;      // FCH: output-channel fragments of ONE wave (half of d / 16)
@@ -437,6 +455,11 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
   uint2 mine[FP];
 #pragma unroll
   for (int f = 0; f < FP; ++f) mine[f] = uint2{0u, 0u};
+  unsigned hpoff[HP ? FP : 1];            // HP: byte offset of (pixel, hidden 8 lq + 4 hh) in hpre; the host keeps M * 8 D below 2^32
+  if constexpr (HP) {
+#pragma unroll
+    for (int f = 0; f < FP; ++f) hpoff[f] = (unsigned)(pbase + f * 16 + lr) * (unsigned)(8 * D) + (unsigned)(lq * 16 + hh * 8);
+  }
   stage(0, 0);
 #pragma unroll 1
   for (int j0 = 0; j0 <= NCH; j0 += 2) {
@@ -476,6 +499,11 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
 #pragma unroll
         for (int f = 0; f < FP; ++f) {
           f32x2_t a01 = f32x2_t{h[f][0] + bv.x, h[f][1] + bv.y}, a23 = f32x2_t{h[f][2] + bv.z, h[f][3] + bv.w};
+          if constexpr (HP) {           // this wave's 4 hidden units 8 lq + 4 hh .. + 3 of the chunk (training weight order), pre-activation
+            // (address = scalar chunk base + one 32-bit lane offset per pixel block: the kernel has no registers to spare for 64-bit pointers)
+            if (pbase + f * 16 + lr < p.M)
+              *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.hpre) + (size_t)(j * 64) + (size_t)hpoff[f]) = uint2{pk2<HT>(a01.x, a01.y), pk2<HT>(a23.x, a23.y)};
+          }
           if (!MLP_ABL(p, 1)) { a01 = gelu_poly2(a01); a23 = gelu_poly2(a23); }
           mine[f] = uint2{pk2<HT>(a01.x, a01.y), pk2<HT>(a23.x, a23.y)};
           xch[u * (4 * 2 * FP * 64) + xmine + f * 64] = mine[f];
@@ -499,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
   }
 }
 
-template <int D, typename HT, bool ORD = false>
+template <int D, typename HT, bool ORD = false, bool HP = false>
 int launch_mlp_pair(const MlpP& p, hipStream_t s) {
   constexpr int P = 4 * 2 * 16;
   constexpr int STAGE = 32 * D * 2 + D * 64;
@@ -507,8 +535,8 @@ int launch_mlp_pair(const MlpP& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   const long blocks = ((long)p.M + P - 1) / P;
   if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
-  if (int rc = mtbt_allow_lds(mlp_pair_kernel<D, HT, ORD>, lds)) return rc;
-  hipLaunchKernelGGL((mlp_pair_kernel<D, HT, ORD>), dim3((unsigned)blocks), dim3(512), lds, s, p);
+  if (int rc = mtbt_allow_lds(mlp_pair_kernel<D, HT, ORD, HP>, lds)) return rc;
+  hipLaunchKernelGGL((mlp_pair_kernel<D, HT, ORD, HP>), dim3((unsigned)blocks), dim3(512), lds, s, p);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }
@@ -684,8 +712,9 @@ int launch_mlp_resident(const MlpP& p, hipStream_t s) {
 // residual stream does not need).  w1 [4D][D] bf16, b1 [4D] f32, w2p [D][4D] bf16 with the per-32 hidden permutation,
 // b2 [D] f32.  D in {96, 192}.
 static int mlp_entry(const void* t, const void* res, const void* w1, const float* b1, const void* w2p, const float* b2, void* y, int64_t M, int D,
-                     int dtype, void* stream) {
+                     int dtype, void* stream, void* hpre = nullptr) {
   if (!t || !w1 || !b1 || !w2p || !b2 || !y || M <= 0 || M > 0x7fffff00L) return MTBT_EINVAL;
+  if (hpre && (dtype != MTBT_BF16 || !aligned16(hpre) || M * 8 * (int64_t)D >= 0xffff0000L)) return MTBT_EINVAL;
   if (dtype != MTBT_BF16 && dtype != MTBT_F16) return MTBT_EINVAL;
   if (D != 96 && D != 192 && D != 384) return MTBT_EINVAL;
   if (!aligned16(t) || !aligned16(w1) || !aligned16(w2p) || !aligned16(y) || !aligned16(b1) || (res && !aligned16(res))) return MTBT_EALIGN;
@@ -694,6 +723,7 @@ static int mlp_entry(const void* t, const void* res, const void* w1, const float
   p.t = reinterpret_cast<const bf16_t*>(t); p.w1 = reinterpret_cast<const bf16_t*>(w1); p.b1 = b1;
   p.w2p = reinterpret_cast<const bf16_t*>(w2p); p.M = (int)M;
   p.dbg = 0;   // ablation bits: development builds only (the library reads no environment variables)
+  p.hpre = reinterpret_cast<bf16_t*>(hpre);
   ConvP& e = p.ep;
   e = ConvP{};
   p.res = (p.dbg & 16) ? nullptr : reinterpret_cast<const bf16_t*>(res);
@@ -711,6 +741,11 @@ static int mlp_entry(const void* t, const void* res, const void* w1, const float
   // the one-off 147 KB weight stage per CU); small calls (tests, tiny maps) keep the streaming kernel
   if (D == 96 && M >= 64 * 1024 && M * 96 < 0x7fffffffL && MTBT_MLP_RESIDENT)
     return dtype == MTBT_F16 ? launch_mlp_resident<96, f16_t, 8, true>(p, s) : launch_mlp_resident<96, bf16_t, 8, true>(p, s);
+  if (hpre) {   // training forward (bf16): the same kernels with the pre-activation store compiled in
+    if (D == 384) return MTBT_EINVAL;   // (the pair kernel has no registers for the store: 208 spills -- stage 2 trains through the two GEMMs)
+    if (D == 192) return launch_mlp<192, 2, 2, bf16_t, true, true>(p, s);
+    return launch_mlp<96, 2, 4, bf16_t, false, true>(p, s);
+  }
   // round 3 (tools/mlp_variants.py, bit-identical outputs): d = 384 in the pair form 96 us against 122; d = 192 with the pipelined chunk
   // 95 against 101 (the pair form there: 131 -- at d = 192 two waves per SIMD already fit without it and the exchange is pure overhead)
   if (D == 384) return dtype == MTBT_F16 ? launch_mlp_pair<384, f16_t>(p, s) : launch_mlp_pair<384, bf16_t>(p, s);
@@ -727,4 +762,15 @@ extern "C" int mtbt_convnext_mlp_fused(const void* t, const void* res, const voi
 extern "C" int mtbt_convnext_mlp_fused_dt(const void* t, const void* res, const void* w1, const float* b1, const void* w2p,
                                           const float* b2, void* y, int64_t M, int D, int dtype, void* stream) {
   return mlp_entry(t, res, w1, b1, w2p, b2, y, M, D, dtype, stream);
+}
+
+// Training forward of the ConvNeXt Mlp (bf16): y as above, plus the fc1 PRE-activation hpre [M][4D] (bf16, natural hidden order) that the
+// backward reads (GELU' in the fc2 input gradient; GELU re-applied while the fc2 weight gradient stages it) -- the activated hidden tensor
+// itself is never written.  Weight order of THIS entry: w1 rows (and b1) permuted per 32-row chunk -- staged row 16 blk + 4 q + e holds
+// hidden unit 8 q + 4 blk + e -- and w2 [D][4D] in natural column order (layer scale folded into its rows): with that order a lane's
+// 4 + 4 GEMM1 accumulators are 8 CONSECUTIVE hidden units, i.e. GEMM2's B fragment in natural order and one 16-byte store of hpre.
+extern "C" int mtbt_convnext_mlp_fused_train(const void* t, const void* res, const void* w1_perm, const float* b1_perm, const void* w2, const float* b2,
+                                             void* y, void* hpre, int64_t M, int D, void* stream) {
+  if (!hpre) return MTBT_EINVAL;
+  return mlp_entry(t, res, w1_perm, b1_perm, w2, b2, y, M, D, MTBT_BF16, stream, hpre);
 }

@@ -50,12 +50,32 @@ __device__ __forceinline__ int tile_off(int row, int col) {   // element offset 
   return row * 128 + (swz_unit(row, col >> 4) << 4) + (col & 15);
 }
 
+// GELU (gelu_poly of common.h, evaluated on packed pairs) of the 8 bf16 values of a 16-byte piece
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gelu2_bf16(uint32_t u) {
+  const f32x2w x = f32x2w{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  const f32x2w xc = f32x2w{__builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f)};
+  const f32x2w s = xc * xc;
+  auto k = [](float c) { return f32x2w{c, c}; };
+  f32x2w q = __builtin_elementwise_fma(k(2.1609857e-08f), s, k(-1.5335673e-06f));
+  q = __builtin_elementwise_fma(q, s, k(4.6542096e-05f));
+  q = __builtin_elementwise_fma(q, s, k(-7.9887325e-04f));
+  q = __builtin_elementwise_fma(q, s, k(8.6900834e-03f));
+  q = __builtin_elementwise_fma(q, s, k(-6.4366050e-02f));
+  q = __builtin_elementwise_fma(q, s, k(3.9770728e-01f));
+  const f32x2w g = x * __builtin_elementwise_fma(xc, q, k(0.5f));
+  return (uint32_t)f2bf(g.x) | ((uint32_t)f2bf(g.y) << 16);
+}
+__device__ __forceinline__ uint4 gelu8_bf16(uint4 v) { return uint4{gelu2_bf16(v.x), gelu2_bf16(v.y), gelu2_bf16(v.z), gelu2_bf16(v.w)}; }
+
 // NK x NC: the tile is (128 NK output channels) x (128 NC input channels), each of the 2 x 2 waves 64 NK x 64 NC.  (1, 1) is the base
 // form.  The GEMM-shaped gradients of the ConvNeXt MLPs (K, C = 384 .. 3072 at 12 800 .. 204 800 pixels) are bound by operand traffic, not
 // MFMA time: a 128 x 128 tile does 64 FLOP per byte it stages and ran at 360 TFLOP/s = 5.6 TB/s out of L2 / Infinity Cache; (2, 1) / (1, 2)
 // stage 3/4 of the bytes for twice the MFMAs (85 FLOP/B) at the price of 128 accumulator registers.  The wide side is laid out as two
 // 128-column panels of the base LDS image.
-template <bool BIAS, int NK, int NC>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
+// XACT: the X operand is a PRE-activation and GELU (the bf16 forward's polynomial form) is applied while it is staged -- the fc2 weight gradient of a
+// ConvNeXt block whose fused forward never wrote the activated hidden tensor (mtbt_convnext_mlp_fused_train).
+template <bool BIAS, int NK, int NC, bool XACT = false>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
   constexpr int TKt = TK * NK, TCt = TCH * NC, FA = 4 * NK, FB = 4 * NC;
   __shared__ __attribute__((aligned(16))) bf16_t sdy[TPX * TKt];
@@ -137,7 +157,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
       for (int h = 0; h < NK; ++h) *reinterpret_cast<uint4*>(sdy + h * (TPX * 128) + tile_off(tr, chunk * 8)) = vdy[h][i];
 #pragma unroll
-      for (int h = 0; h < NC; ++h) *reinterpret_cast<uint4*>(sx + h * (TPX * 128) + tile_off(tr, chunk * 8)) = vx[h][i];
+      for (int h = 0; h < NC; ++h) {
+        if constexpr (XACT) vx[h][i] = gelu8_bf16(vx[h][i]);
+        *reinterpret_cast<uint4*>(sx + h * (TPX * 128) + tile_off(tr, chunk * 8)) = vx[h][i];
+      }
     }
     __syncthreads();
     if (pb + TPX < p1) fetch(pb + TPX);                // the next step's global loads are in flight during this step's MFMAs
@@ -581,7 +604,8 @@ extern "C" int64_t mtbt_conv_wgrad_workspace_bytes(int N, int H, int W, int C, i
 
 static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
                        int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
-                       int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+                       int accumulate, void* workspace, int64_t workspace_bytes, void* stream, int x_act = MTBT_ACT_NONE) {
+  if (x_act != MTBT_ACT_NONE && (x_act != MTBT_ACT_GELU_POLY || dtype != MTBT_BF16 || dbias || R != 1 || S != 1)) return MTBT_EINVAL;
   if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return MTBT_EINVAL;
   if (dtype != MTBT_BF16 && dtype != MTBT_F32) return MTBT_EINVAL;
   const int epc = dtype == MTBT_BF16 ? 8 : 4;   // elements per 16-byte piece
@@ -656,7 +680,11 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
     else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, p);     \
     else hipLaunchKernelGGL((wgrad_kernel<B_, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);                  \
   } while (0)
-  if (dbias) WG(true); else WG(false);
+  if (x_act == MTBT_ACT_GELU_POLY) {
+    if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 1, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_kernel<false, 1, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  } else if (dbias) WG(true); else WG(false);
 #undef WG
   launch_wgrad_reduce(p.partial, dw, n, p.nsplit, accumulate, st);
   if (dbias) launch_wgrad_reduce(bpartial, dbias, (long)K, p.nsplit, accumulate, st);
@@ -669,6 +697,15 @@ extern "C" int mtbt_conv_wgrad(const void* x, const void* dy, float* dw, int N, 
                                int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   return wgrad_entry(x, dy, dw, nullptr, N, H, W, C, K, R, S, pad, stride, x_batch_stride, x_pixel_stride, dy_batch_stride, dy_pixel_stride, dtype,
                      accumulate, workspace, workspace_bytes, stream);
+}
+
+// The same with an activation applied to x while it is staged: x_act = MTBT_ACT_GELU_POLY (bf16, 1 x 1) -- x is the fc1 PRE-activation kept by
+// mtbt_convnext_mlp_fused_train and dw the fc2 weight gradient  dW2[k][c] = sum_p dy[p][k] * gelu(x[p][c]).
+extern "C" int mtbt_conv_wgrad_xact(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int K, int R, int S, int pad, int stride,
+                                    int64_t x_batch_stride, int32_t x_pixel_stride, int64_t dy_batch_stride, int32_t dy_pixel_stride, int dtype,
+                                    int x_act, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return wgrad_entry(x, dy, dw, nullptr, N, H, W, C, K, R, S, pad, stride, x_batch_stride, x_pixel_stride, dy_batch_stride, dy_pixel_stride, dtype,
+                     accumulate, workspace, workspace_bytes, stream, x_act);
 }
 
 // The same plus the BIAS gradient dbias[k] (+)= sum_p dy[p][k] from the dY fragments the kernel holds anyway (no extra pass over dy).

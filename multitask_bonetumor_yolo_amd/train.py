@@ -31,6 +31,7 @@ from .engine import Act, ESIZE, Launch, Plan, TORCH_DTYPE, _region
 
 # column sums from the conv epilogue (BatchNorm batch statistics, d fc1.bias) instead of separate passes; MTBT_FUSED_COLSUM=0 turns them off (A/B)
 FUSED_BN_STATS = os.environ.get("MTBT_FUSED_COLSUM", "1") != "0"
+FUSED_TRAIN_MLP = os.environ.get("MTBT_TRAIN_FUSED_MLP", "1") != "0"      # ConvNeXt Mlp forward of stages 0-1 as one launch (bf16), see TrainPlan
 
 WS_BYTES = 256 << 20           # shared scratch of the reduction kernels (sequential plan)
 CLS_PAD = 32                   # the nc-channel class conv's gradient operand is zero-padded to this many channels
@@ -187,19 +188,32 @@ class TPlan(Plan):
                  writes=[dx, dgamma, dbeta, self.cur_ws])
         self.est(5.0 * pixels * x.C * ESIZE[x.code])
 
-    def wgrad(self, x: Act, dy: Act, out: torch.Tensor, *, R, S, pad, stride=1, dbias: Optional[torch.Tensor] = None, name="wgrad"):
-        """dW (and, with `dbias`, sum_p dy -- the bias gradient, from the same launch)."""
+    def wgrad(self, x: Act, dy: Act, out: torch.Tensor, *, R, S, pad, stride=1, dbias: Optional[torch.Tensor] = None, x_act: int = 0, name="wgrad"):
+        """dW (and, with `dbias`, sum_p dy -- the bias gradient, from the same launch).  `x_act`: x is a pre-activation, the activation is
+        applied while it is staged (mtbt_conv_wgrad_xact)."""
         assert x.code == dy.code and x.N == dy.N and out.dtype == torch.float32 and out.is_contiguous()
         assert out.numel() == dy.C * R * S * x.C, (out.shape, dy.C, R, S, x.C)
         assert dbias is None or (dbias.numel() == dy.C and dbias.dtype == torch.float32)
         nbytes = self.lib.mtbt_conv_wgrad_workspace_bytes(x.N, max(x.H, dy.H), max(x.W, dy.W), x.C, dy.C, R, S)
         tail = (x.N, x.H, x.W, x.C, dy.C, R, S, pad, stride, x.batch_stride, x.ld, dy.batch_stride, dy.ld, x.code, 0, self._ws(nbytes), nbytes)
-        if dbias is None:
+        if x_act:
+            assert dbias is None
+            args = (x.ptr, dy.ptr, out.data_ptr()) + tail[:14] + (x_act,) + tail[14:]
+            self.raw(self.lib.mtbt_conv_wgrad_xact, args, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.cur_ws])
+        elif dbias is None:
             self.raw(self.lib.mtbt_conv_wgrad, (x.ptr, dy.ptr, out.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out), reads=[x, dy], writes=[out, self.cur_ws])
         else:
             self.raw(self.lib.mtbt_conv_wgrad_bias, (x.ptr, dy.ptr, out.data_ptr(), dbias.data_ptr()) + tail, name, keep=(x.buf, dy.buf, out, dbias),
                      reads=[x, dy], writes=[out, dbias, self.cur_ws])
         self.est(1.0 * dy.N * dy.H * dy.W * (dy.C + x.C) * ESIZE[x.code], 2.0 * dy.N * dy.H * dy.W * dy.C * R * S * x.C)
+
+    def mlp_fused_train(self, t: Act, res: Act, w1p, b1p, w2, b2, y: Act, hpre: Act, name):
+        """ConvNeXt Mlp forward in one launch, keeping only the fc1 pre-activation (mtbt_convnext_mlp_fused_train)."""
+        assert t.dense and res.dense and y.dense and hpre.dense and t.code == L.BF16 and hpre.C == 4 * t.C
+        M, d = t.N * t.H * t.W, t.C
+        self.raw(self.lib.mtbt_convnext_mlp_fused_train, (t.ptr, res.ptr, w1p.data_ptr(), b1p.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.ptr, hpre.ptr, M, d),
+                 name, keep=(t.buf, res.buf, w1p, b1p, w2, b2, y.buf, hpre.buf), reads=[t, res, w1p, b1p, w2, b2], writes=[y, hpre])
+        self.est(2.0 * M * d * (3 + 4), 16.0 * M * d * d)
 
     def channel_sum(self, x: Act, out: torch.Tensor, times: Optional[Act] = None, name="channel_sum"):
         assert x.bs == x.H * x.W * x.ld and (times is None or (times.bs == times.H * times.W * times.ld and times.code == x.code))
@@ -717,12 +731,18 @@ class TrainPlan:
         for p_, n_ in ((blk.conv_dw.bias, "conv_dw.bias"), (blk.norm.weight, "norm.weight"), (blk.norm.bias, "norm.bias"), (fc1.bias, "fc1.bias"),
                        (fc2.bias, "fc2.bias"), (gamma, "gamma"), (fc2.weight, "fc2.weight")):
             _dense_vec(p_, f"{name}.{n_}")
-        w1f, w1d = self.w_fwd(fc1.weight), self.w_dgrad(fc1.weight)
-        w2f = self.w_fwd(fc2.weight)
+        fused_mlp = T == L.BF16 and d in (96, 192) and FUSED_TRAIN_MLP and fc1.weight.is_contiguous() and fc2.weight.is_contiguous()   # (below)
+        w1d = self.w_dgrad(fc1.weight)
+        w1f, w2f = (None, None) if fused_mlp else (self.w_fwd(fc1.weight), self.w_fwd(fc2.weight))
         w2d = self.prep_w(fc2.weight, (4 * d, 1, 1, d), (fc2.weight.stride(1), 0, 0, fc2.weight.stride(0)), scale0=(gamma, 3)).view(4 * d, d)
         shift2 = self.prep_w(fc2.bias, (1, 1, 1, d), (0, 0, 0, 1), scale0=(gamma, 3), dtype=torch.float32).view(d)   # gamma * b2
         r, t = self.new(N, H, W, d), self.new(N, H, W, d)
-        h, hpre = self.new(N, H, W, 4 * d), self.new(N, H, W, 4 * d)
+        # bf16, d = 96 / 192: fc1 -> GELU -> fc2 as ONE launch that keeps only the fc1 pre-activation (mtbt_convnext_mlp_fused_train): the 4d-wide
+        # activated tensor is neither written nor read back (stage 0 at batch 32: 2 x 629 MB per block) and is not kept for the backward --
+        # the fc2 weight gradient re-applies GELU while it stages hpre.  Wider stages keep the two GEMMs (d = 384: the pair kernel has no
+        # registers left for the store; d = 768: no fused kernel).  MTBT_TRAIN_FUSED_MLP=0 restores the two GEMMs everywhere.
+        hpre = self.new(N, H, W, 4 * d)
+        h = None if fused_mlp else self.new(N, H, W, 4 * d)
         y = self.new(N, H, W, d)
         self.fwd.dwconv_t(cur, taps, t, 7, bias=blk.conv_dw.bias, lnw=blk.norm.weight, lnb=blk.norm.bias, eps=blk.norm.eps, raw=r,
                           name=name + ".conv_dw+norm")
@@ -730,8 +750,16 @@ class TrainPlan:
         # backward, the EXACT derivative of that polynomial -- no erf / exp in either epilogue (round 3: the erf forms made the epilogues
         # of fc1 and of fc2-dgrad VALU-bound at stage 2); the fp32 parity mode keeps the erf forms
         poly = T != L.F32
-        self.fwd.conv2(t, w1f, h, shift=fc1.bias, act=L.ACT_GELU_POLY if poly else L.ACT_GELU, y2=hpre, name=name + ".mlp.fc1")
-        self.fwd.conv(h, w2f, y, scale=gamma, shift=shift2, res=cur, name=name + ".mlp.fc2")
+        if fused_mlp:
+            nj = 4 * d // 32
+            # staged row 16 b + 4 g + e of a 32-row chunk = hidden unit 8 g + 4 b + e (header): [chunk][b][g][e * d + column] over the row-major weight
+            w1p = self.prep_w(fc1.weight, (nj, 2, 4, 4 * d), (32 * d, 4 * d, 8 * d, 1)).view(4 * d, d)
+            b1p = self.prep_w(fc1.bias, (nj, 2, 4, 4), (32, 4, 8, 1), dtype=torch.float32, what="bias").view(4 * d)
+            w2g = self.prep_w(fc2.weight, (d, 1, 1, 4 * d), (fc2.weight.stride(0), 0, 0, fc2.weight.stride(1)), scale0=(gamma, 0)).view(d, 4 * d)
+            self.fwd.mlp_fused_train(t, cur, w1p, b1p, w2g, shift2, y, hpre, name + ".mlp(fused)")
+        else:
+            self.fwd.conv2(t, w1f, h, shift=fc1.bias, act=L.ACT_GELU_POLY if poly else L.ACT_GELU, y2=hpre, name=name + ".mlp.fc1")
+            self.fwd.conv(h, w2f, y, scale=gamma, shift=shift2, res=cur, name=name + ".mlp.fc2")
         gtmp = torch.empty(d, 4 * d, dtype=torch.float32, device=self.device)
         ssum = torch.empty(d, dtype=torch.float32, device=self.device)
         one, zero = self.ones(d)
@@ -743,7 +771,10 @@ class TrainPlan:
             # (sum_p dy and the fc1 bias gradient stay separate channel sums: in these GEMM-shaped weight gradients EVERY workgroup would
             #  carry the 25 % extra MFMAs of the fused form -- measured +2.0 ms against the 2.8 ms of the two sums)
             self.bwd.channel_sum(dy, ssum, name=name + ".sum_dy")
-            self.bwd.wgrad(h, dy, gtmp, R=1, S=1, pad=0, name=name + ".fc2.wgrad")
+            if fused_mlp:
+                self.bwd.wgrad(hpre, dy, gtmp, R=1, S=1, pad=0, x_act=L.ACT_GELU_POLY, name=name + ".fc2.wgrad")
+            else:
+                self.bwd.wgrad(h, dy, gtmp, R=1, S=1, pad=0, name=name + ".fc2.wgrad")
             dW2, dg, db2 = self.pg(fc2.weight), self.pg(gamma), self.pg(fc2.bias)
             self.bwd.raw(self.lib.mtbt_scale_grad, (0, gtmp.data_ptr(), fc2.weight.data_ptr(), gamma.data_ptr(), fc2.bias.data_ptr(), ssum.data_ptr(),
                                                     dW2.data_ptr(), dg.data_ptr(), db2.data_ptr(), d, 4 * d, 0), name + ".fc2.scale_grad",

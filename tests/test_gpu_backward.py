@@ -107,6 +107,29 @@ def test_conv_wgrad(N, H, W, C, K, k):
     assert torch.allclose(acc, 2 * got, rtol=1e-5, atol=1e-5 * scale)                # (dw + partials) rounds differently from 2 * dw
 
 
+@pytest.mark.parametrize("P,C,K", [(2 * 9 * 7, 384, 96), (3 * 8 * 8, 768, 192), (130, 256, 256)])
+def test_conv_wgrad_with_gelu_applied_to_the_staged_operand(P, C, K):
+    """mtbt_conv_wgrad_xact: dW[k][c] = sum_p dy[p][k] * gelu(x[p][c]) with x the kept fc1 PRE-activation (the fc2 weight gradient behind the fused
+    training forward) equals the plain kernel on the activated tensor rounded to bf16 -- both tile orientations."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    g = torch.Generator().manual_seed(P + C)
+    x = (torch.randn(1, P, 1, C, generator=g) * 2).bfloat16()
+    dy = torch.randn(1, P, 1, K, generator=g).bfloat16()
+    h = torch.nn.functional.gelu(x.float()).bfloat16()
+    want = dy.float().view(P, K).t() @ h.float().view(P, C)
+    lib = L.load()
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    out = torch.zeros(K, C, dtype=torch.float32, device=DEV)
+    nbytes = lib.mtbt_conv_wgrad_workspace_bytes(1, P, 1, C, K, 1, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    rc = lib.mtbt_conv_wgrad_xact(xd.data_ptr(), dyd.data_ptr(), out.data_ptr(), 1, P, 1, C, K, 1, 1, 0, 1, P * C, C, P * K, K, L.BF16, L.ACT_GELU_POLY, 0,
+                                  ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    scale = want.abs().max().item()
+    assert (out.cpu() - want).abs().max().item() <= 6e-3 * scale          # the polynomial GELU (2.3e-4 absolute) and one bf16 rounding of h
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", ["silu", "elu", "gelu", "none"])
 def test_act_backward(dtype, act):

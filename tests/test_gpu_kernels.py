@@ -364,6 +364,42 @@ def test_convnext_mlp_fused(D, M):
     assert ((y.float().cpu() - ref).norm() / ref.norm()).item() < 5e-3
 
 
+def _perm_rows_train(n4d):
+    """Row order of mtbt_convnext_mlp_fused_train's fc1 weight / bias (header): staged row 16 b + 4 g + e of a 32-row chunk = hidden 8 g + 4 b + e."""
+    idx = torch.arange(n4d).view(-1, 4, 2, 4)            # [chunk][g][b][e] natural
+    return idx.permute(0, 2, 1, 3).reshape(-1)           # [chunk][b][g][e] staged
+
+
+@pytest.mark.parametrize("D,M", [(96, 200), (192, 333), (96, 4096)])
+def test_convnext_mlp_fused_train_keeps_the_pre_activation(D, M):
+    """Training forward of the ConvNeXt Mlp in one launch (timm Mlp under model.train(), main_model.py:21-26): y as the inference kernel's, plus
+    hpre = fc1(t) + b1 in NATURAL hidden order (bf16) -- what the backward reads.  Ragged M: nothing is written past row M."""
+    from multitask_bonetumor_yolo_amd import _lib as L
+    g = torch.Generator().manual_seed(D + M)
+    t = torch.randn(M, D, generator=g).bfloat16()
+    res = torch.randn(M, D, generator=g).bfloat16()
+    w1 = (torch.randn(4 * D, D, generator=g) / D ** 0.5).bfloat16()
+    w2 = (torch.randn(D, 4 * D, generator=g) / (4 * D) ** 0.5 * 0.1).bfloat16()
+    b1, b2 = torch.randn(4 * D, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    pre = t.float() @ w1.float().t() + b1
+    ref = res.float() + torch.nn.functional.gelu(pre).bfloat16().float() @ w2.float().t() + b2
+    perm = _perm_rows_train(4 * D)
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    hp = torch.full((M + 3, 4 * D), 7.0, dtype=torch.bfloat16, device=DEV)
+    dev = [v.to(DEV) for v in (t, res, w1[perm].contiguous(), b1[perm].contiguous(), w2, b2)]
+    lib = L.load()
+    rc = lib.mtbt_convnext_mlp_fused_train(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
+                                           dev[5].data_ptr(), y.data_ptr(), hp.data_ptr(), M, D, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert ((y.float().cpu() - ref).norm() / ref.norm()).item() < 5e-3
+    got = hp.float().cpu()
+    assert torch.all(got[M:] == 7.0)
+    assert (got[:M] - pre).abs().max().item() <= 2 ** -7 * max(1.0, pre.abs().max().item())          # bf16 rounding of the stored value
+    assert lib.mtbt_convnext_mlp_fused_train(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), dev[5].data_ptr(),
+                                             y.data_ptr(), None, M, D, torch.cuda.current_stream().cuda_stream) == -1      # MTBT_EINVAL: hpre is what this entry is for
+
+
 def test_fp16_store_saturates_and_keeps_nan():
     """The fp16 arithmetic mode's stores (common.h f2h_bits, BASELINE configs[4]): finite values beyond the binary16 range saturate at
     +-65504, infinities too, and a NaN stays a NaN (v_med3_f32 alone would have returned -65504 for it and hidden a divergence)."""

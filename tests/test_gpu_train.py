@@ -335,6 +335,34 @@ def test_gradient_accumulation_over_two_backward_passes_fp32():
         assert kept is dict(hip.named_parameters())[n].grad and not torch.equal(kept, old)
 
 
+def test_bf16_fused_mlp_lowering_agrees_with_the_two_gemm_lowering(monkeypatch):
+    """bf16 training plan: stages 0-1 run the ConvNeXt Mlp as one launch that keeps only the fc1 pre-activation (mtbt_convnext_mlp_fused_train,
+    the fc2 weight gradient re-applies GELU while staging it).  Against the same plan built with MTBT_TRAIN_FUSED_MLP=0 (fc1 / fc2 as two GEMMs, the
+    activated tensor kept): outputs and the block's parameter gradients agree to bf16 accuracy."""
+    import importlib
+    from multitask_bonetumor_yolo_amd import train as T
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(T, "FUSED_TRAIN_MLP", fused)
+        _, hip = build("main", seed=6, train=False)      # BatchNorm on running statistics: no batch-of-2 statistics to amplify rounding differences
+        hip.set_compute_dtype(torch.bfloat16)
+        det, (seg, mc, protos), logits = hip(x, "train")
+        names = [l.name for l in next(iter(hip._train_plans.values())).fwd.launches]
+        assert any("mlp(fused)" in n for n in names) == fused
+        (sum(d.float().mean() for d in det) + protos.float().mean() + logits.float().sum()).backward()
+        torch.cuda.synchronize()
+        gr = {n: p.grad.float().clone() for n, p in hip.named_parameters() if p.grad is not None and ("stages_0.blocks.0" in n or "stages_1.blocks.2" in n)}
+        res[fused] = ([d.float().clone() for d in det] + [protos.float().clone(), logits.float().clone()], gr)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a - b).norm().item() <= 3e-2 * b.norm().item() + 1e-3
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) >= 10
+    for n, gb in res[False][1].items():
+        ga = res[True][1][n]
+        cos = torch.nn.functional.cosine_similarity(ga.flatten(), gb.flatten(), dim=0).item()
+        assert cos >= 0.97 or gb.norm().item() < 1e-6, (n, cos)
+
+
 def test_forward_follows_the_trainers_autocast():
     """`precision="bf16-mixed"` (running_main_v3.py:825): Lightning wraps forward in autocast("cuda", bfloat16).  A drop-in whose arithmetic
     mode was never pinned follows it -- the bf16 training / inference plans are the ones lowered and run, the outputs stay fp32 tensors, the

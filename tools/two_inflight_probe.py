@@ -3,14 +3,18 @@ the tail of step i (small pyramid-level launches that do not fill the chip) over
 import copy, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLO, GraphedInference, init_synthetic_
+from multitask_bonetumor_yolo_amd.model import calibrate_synthetic_heads_, synthetic_images
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 mA = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
 mA.set_compute_dtype(torch.bfloat16)
-mB = copy.deepcopy(mA)
 B, IMG = 16, 640
-xA = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(0)).to(dev)
-xB = torch.rand(B, 3, IMG, IMG, generator=torch.Generator().manual_seed(1)).to(dev)
+xA = synthetic_images(B, IMG, 0).to(dev)
+xB = synthetic_images(B, IMG, 1).to(dev)
+calibrate_synthetic_heads_(mA, xA)
+mB = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(dev).eval()
+mB.load_state_dict(mA.state_dict())
+mB.set_compute_dtype(torch.bfloat16)
 gA, gB = GraphedInference(mA, xA, IMG), GraphedInference(mB, xB, IMG)
 sA, sB = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 def run(n, two):
