@@ -174,7 +174,12 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
 // MODE 0: y = act(affine) (+ res);  1: y2 = affine (pre-activation), y = act(affine) (+ res);  2: y = affine * act'(res)  (ACT = MTBT_ACT_D*)
 struct EpiSeq { long pix0; int jstep; long npix; long ybias, rbias; };
 
-template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false>
+// RESPF: the residual / pre-activation pieces of the WHOLE tile are requested before the first slab is written.  With the load next to each
+// store (res may BE y: a gradient accumulating into its own buffer) every piece waits for its own round trip -- the compiler cannot move a
+// load above the previous, possibly aliasing, store: FP x ITER dependent latencies per tile (round 3: found in the depthwise kernel first,
+// where the same pattern cost 40 % of the input-gradient launches).  Reading everything first is safe under aliasing: a lane reads exactly the
+// locations it writes later, and tiles are disjoint.  Implicit-GEMM kernels only (FP x ITER x 4 registers; the direct kernels have none to spare).
+template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, bool RESPF = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase, int chl0, int lane,
                                                    const EpiSeq q, long srow = -1) {
   constexpr int WCH = FC * 16;
@@ -216,6 +221,18 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
   HT* const yp = reinterpret_cast<HT*>(p.y);
   HT* const y2p = reinterpret_cast<HT*>(p.y2);
   const T* const rp = reinterpret_cast<const T*>(p.res);
+  uint4 rpf[RESPF ? FP : 1][RESPF ? ITER : 1];
+  if constexpr (RESPF) {
+    if (MODE == 2 || has_res) {
+#pragma unroll
+      for (int j = 0; j < FP; ++j)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          rpf[j][it] = uint4{0u, 0u, 0u, 0u};
+          if (ok[it] && px[it] + (long)j * q.jstep < q.npix) rpf[j][it] = *reinterpret_cast<const uint4*>(rp + ro[it] + j * rstep);
+        }
+    }
+  }
 #pragma clang loop unroll(full)
   for (int j = 0; j < FP; ++j) {
 #pragma unroll
@@ -248,12 +265,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
       }
       if (MODE == 2) {
         float r[8];
-        ld8<T>(rp + roff, r);
+        if constexpr (RESPF) ld8<T>(reinterpret_cast<const T*>(&rpf[RESPF ? j : 0][RESPF ? it : 0]), r); else ld8<T>(rp + roff, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= act_grad(r[e], ACT);
       } else if (has_res) {
         float r[8];
-        ld8<T>(rp + roff, r);
+        if constexpr (RESPF) ld8<T>(reinterpret_cast<const T*>(&rpf[RESPF ? j : 0][RESPF ? it : 0]), r); else ld8<T>(rp + roff, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += r[e];
       }
@@ -274,15 +291,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq seq, bool use_seq,
                                               long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {
   // (seq by VALUE: behind a conditional pointer the struct was materialised in scratch memory in the fp16 kernels)
-#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV>(p, acc, slab, aff, cbase, chl0, lane, seq)
+#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, TRAIN>(p, acc, slab, aff, cbase, chl0, lane, seq)
   // (fp32 storage always writes fp32: the fast bodies -- 16-bit outputs -- are not even compiled for it)
   const bool fast = sizeof(T) == 2 && use_seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
   constexpr bool CS_OK = (((FC * 16) / 8) & ((FC * 16) / 8 - 1)) == 0;
   if constexpr (sizeof(T) == 2) {
   if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
-    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, TRAIN>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
     // (16-bit storage: the polynomial derivative has the compiled body; MTBT_ACT_DGELU falls through to the general one)
-    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, TRAIN>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
   } else if (fast && !(TRAIN && p.y2)) {
     switch (p.act) {
       case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;
