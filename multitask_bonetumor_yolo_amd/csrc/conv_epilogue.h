@@ -286,20 +286,20 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
 }
 
 // Dispatcher: ONE switch per call.  `seq` non-null = the caller's output pixels form the arithmetic sequence the fast body wants.
-template <typename T, int TC, int FC, int FP, bool TRAIN = true, typename AddrFn>
+template <typename T, int TC, int FC, int FP, bool TRAIN = true, bool RESPF = TRAIN, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq seq, bool use_seq,
                                               long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {
   // (seq by VALUE: behind a conditional pointer the struct was materialised in scratch memory in the fp16 kernels)
-#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, TRAIN>(p, acc, slab, aff, cbase, chl0, lane, seq)
+#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, RESPF>(p, acc, slab, aff, cbase, chl0, lane, seq)
   // (fp32 storage always writes fp32: the fast bodies -- 16-bit outputs -- are not even compiled for it)
   const bool fast = sizeof(T) == 2 && use_seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
   constexpr bool CS_OK = (((FC * 16) / 8) & ((FC * 16) / 8 - 1)) == 0;
   if constexpr (sizeof(T) == 2) {
   if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
-    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, TRAIN>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, RESPF>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
     // (16-bit storage: the polynomial derivative has the compiled body; MTBT_ACT_DGELU falls through to the general one)
-    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, TRAIN>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, RESPF>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
   } else if (fast && !(TRAIN && p.y2)) {
     switch (p.act) {
       case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;

@@ -74,18 +74,32 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
   const int iy = (row + 2) >> 2;
   const float wy1 = ((row + 2) & 3) * 0.25f + 0.125f, wy0 = 1.0f - wy1;
 
-  for (int g0 = 0; g0 < cnt; g0 += 16) {
-    // 2a. coefficients of boxes g0..g0+15 (zeros past cnt)
-    for (int i = tid; i < 16 * NM; i += 256) {
-      const int b = i >> 5, c = i & 31;
+  // coefficients of a group of 16 boxes: gather index -> coefficient, two DEPENDENT global loads.  Fetched one group ahead into registers
+  // (two values per thread): with the loads at the top of each group every one of the ~7 groups of an image paid both latencies in front of
+  // its first barrier (round 3).
+  float cpre[2];
+  auto fetch_coef = [&](int g) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + u * 256, b = i >> 5, c = i & 31;
       float v = 0.f;
-      if (g0 + b < cnt) {
-        const long kk = p.gather ? p.gather[(long)n * p.K + g0 + b] : (g0 + b);
+      if (g + b < cnt) {
+        const long kk = p.gather ? p.gather[(long)n * p.K + g + b] : (g + b);
         v = p.coeff[(long)n * p.cbs + kk * p.cks + c * p.ccs];
       }
-      coef[b * PPITCH + c] = v;
+      cpre[u] = v;
+    }
+  };
+  if (cnt > 0) fetch_coef(0);
+  for (int g0 = 0; g0 < cnt; g0 += 16) {
+    // 2a. coefficients of boxes g0..g0+15 (zeros past cnt)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + u * 256;
+      coef[(i >> 5) * PPITCH + (i & 31)] = cpre[u];
     }
     __syncthreads();
+    if (g0 + 16 < cnt) fetch_coef(g0 + 16);            // in flight during this group's MFMAs and upsampling
     // 2b. low[16][NPXP] = coef[16][32] x patch^T on the fp32 MFMA; wave w takes column groups w, w+4, ...
     {
       float a[8];

@@ -75,9 +75,12 @@ __device__ __forceinline__ uint4 gelu8_bf16(uint4 v) { return uint4{gelu2_bf16(v
 // 128-column panels of the base LDS image.
 // XACT: the X operand is a PRE-activation and GELU (the bf16 forward's polynomial form) is applied while it is staged -- the fc2 weight gradient of a
 // ConvNeXt block whose fused forward never wrote the activated hidden tensor (mtbt_convnext_mlp_fused_train).
-template <bool BIAS, int NK, int NC, bool XACT = false>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
-  constexpr int TKt = TK * NK, TCt = TCH * NC, FA = 4 * NK, FB = 4 * NC;
+// WK: waves along the output channels (2: 256 threads; 4: 512 threads, the 256 x 256 tile of the widest GEMM-shaped layers -- each wave still 64 x 128)
+template <bool BIAS, int NK, int NC, bool XACT = false, int WK = 2>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
+__global__ __launch_bounds__(128 * WK, 2) void wgrad_kernel(const WgP p) {
+  constexpr int TKt = TK * NK, TCt = TCH * NC, FA = 8 * NK / WK, FB = 4 * NC;
+  constexpr int RP = 8 * WK, LPT = TPX / RP;            // tile rows staged per pass, passes per step (shadows the file-scope LPT of the 256-thread form)
+  static_assert(FA % 4 == 0 && !(BIAS && WK != 2), "wave tile");
   __shared__ __attribute__((aligned(16))) bf16_t sdy[TPX * TKt];
   __shared__ __attribute__((aligned(16))) bf16_t sx[TPX * TCt];
   // Workgroup -> (pixel slice, tap, tile).  xcd_slices (MTBT_WGRAD_XCD_SLICES, OFF): all tiles of one slice on ONE XCD (consecutive
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
   const int tap = b;
   const int r = tap / p.S, s = tap - r * p.S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave & 1, wc = wave >> 1;            // wave tile: 64 NK output channels x 64 NC input channels
+  const int wk = wave % WK, wc = wave / WK;           // wave tile: 16 FA output channels x 64 NC input channels
   const int row = tid >> 4, chunk = tid & 15;         // staging: tile row (pixel of the pass), 16-byte chunk (8 channels) of a 128-column panel
   const int HW = p.Ho * p.Wo;                       // pixels are those of dY
   const long p0 = (long)split * p.per, p1 = min(p.P, p0 + p.per);
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
   auto fetch = [&](long pb) {   // this thread's 16-byte pieces of the step starting at pixel pb (zeros past the slice / outside the image)
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-      const long pix = pb + i * 16 + row;
+      const long pix = pb + i * RP + row;
 #pragma unroll
       for (int h = 0; h < NK; ++h) vdy[h][i] = uint4{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     __syncthreads();                                   // the previous step's fragment reads are done
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-      const int tr = i * 16 + row;
+      const int tr = i * RP + row;
 #pragma unroll
       for (int h = 0; h < NK; ++h) *reinterpret_cast<uint4*>(sdy + h * (TPX * 128) + tile_off(tr, chunk * 8)) = vdy[h][i];
 #pragma unroll
@@ -176,11 +179,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         B[f] = __builtin_shufflevector(tr_read(base + tile_off(r_lo, cb & 127)), tr_read(base + tile_off(r_hi, cb & 127)), 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int ha = 0; ha < NK; ++ha) {                         // the A fragments four at a time (16 registers live)
+      for (int ha = 0; ha < FA / 4; ++ha) {                     // the A fragments four at a time (16 registers live)
         s16x8 A[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int ca = 64 * NK * wk + 16 * (ha * 4 + f) + 4 * pp;
+          const int ca = 16 * FA * wk + 16 * (ha * 4 + f) + 4 * pp;
           const bf16_t* base = sdy + (ca >> 7) * (TPX * 128);
           A[f] = __builtin_shufflevector(tr_read(base + tile_off(r_lo, ca & 127)), tr_read(base + tile_off(r_hi, ca & 127)), 0, 1, 2, 3, 4, 5, 6, 7);
         }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int k = kt * TKt + 64 * NK * wk + 16 * fa + 4 * (lane >> 4) + e;
+        const int k = kt * TKt + 16 * FA * wk + 16 * fa + 4 * (lane >> 4) + e;
         if (k < p.K) p.bpartial[(long)split * p.K + k] = accb[fa][e];
       }
   }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
       const int c = ct * TCt + 64 * NC * wc + 16 * fb + (lane & 15);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int k = kt * TKt + 64 * NK * wk + 16 * fa + 4 * (lane >> 4) + e;
+        const int k = kt * TKt + 16 * FA * wk + 16 * fa + 4 * (lane >> 4) + e;
         if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)tap * p.C + c] = acc[fa][fb][e];
       }
     }
@@ -566,7 +569,8 @@ static inline void pick_wide(int K, int C, bool allow, int* nk, int* nc) {
   *nk = *nc = 1;
 #if MTBT_WGRAD_WIDE
   if (allow && K > 128 && C > 128) {
-    if (K % 256 == 0 && K >= C) *nk = 2;
+    if (K % 256 == 0 && C % 256 == 0 && (long)K * C >= 384L * 1024) { *nk = 2; *nc = 2; }    // 256 x 256, 512 threads: the stage-2 / stage-3 MLP gradients
+    else if (K % 256 == 0 && K >= C) *nk = 2;
     else if (C % 256 == 0) *nc = 2;
     else if (K % 256 == 0) *nk = 2;
   }
@@ -676,12 +680,14 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
 #define WG(B_)                                                                                                       \
   do {                                                                                                               \
-    if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);          \
+    if (nk == 2 && nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 2, false, 4>), dim3((unsigned)blocks), dim3(512), 0, st, p); \
+    else if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);          \
     else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, p);     \
     else hipLaunchKernelGGL((wgrad_kernel<B_, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);                  \
   } while (0)
   if (x_act == MTBT_ACT_GELU_POLY) {
-    if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (nk == 2 && nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 2, true, 4>), dim3((unsigned)blocks), dim3(512), 0, st, p);
+    else if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 1, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_kernel<false, 1, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
   } else if (dbias) WG(true); else WG(false);

@@ -87,7 +87,8 @@ def test_dwconv_dgrad(dtype, C, k, H):
                                          (2, 9, 7, 384, 512, 1),      # wide tile on the output channels (256 x 128: K % 256 == 0, K >= C), ragged last pixel step
                                          (2, 9, 7, 512, 384, 1),      # wide tile on the input channels (128 x 256)
                                          (1, 12, 12, 256, 256, 1),    # square 256: one wide tile per row
-                                         (1, 6, 6, 256, 192, 3)])     # k x k taps with a wide input side, ragged output-channel tile
+                                         (1, 6, 6, 256, 192, 3),      # k x k taps with a wide input side, ragged output-channel tile
+                                         (1, 12, 11, 768, 512, 1)])   # 256 x 256 tile, 512 threads (the stage-3 MLP shapes)
 def test_conv_wgrad(N, H, W, C, K, k):
     """Weight gradient (csrc/wgrad.hip) vs autograd, bf16-rounded operands, ragged channel tiles and pixel slices."""
     g = torch.Generator().manual_seed(N * H + K + k)
