@@ -25,6 +25,7 @@ class GraphedInference:
         side moves the replay time by +-4 % (a fused kernel that is 15 % faster alone made the step 0.24 ms SLOWER because the prototype
         chain then started later), nothing of which a static cost model sees.  Results do not depend on the schedule."""
         if autotune:
+            import gc
             import time
             opts = dict(model.__dict__.get("plan_options", {}))
 
@@ -39,7 +40,12 @@ class GraphedInference:
                     g.replay()
                 torch.cuda.synchronize(x.device)
                 dt = (time.perf_counter() - t0) / 12
+                # free this candidate before the next is built: its graph's private pool and the plan's buffer pool (32 GB at
+                # batch 64 x 1280^2 -- nine candidates kept alive ran the 288 GB card out of memory, round 3)
                 del g
+                model.__dict__.get("_plans", {}).clear()
+                gc.collect()
+                torch.cuda.empty_cache()
                 return dt
             best = timed(dict(opts))
             if log:

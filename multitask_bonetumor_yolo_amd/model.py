@@ -1131,7 +1131,9 @@ def calibrate_synthetic_heads_(model: nn.Module, x: torch.Tensor, cand_frac: flo
         if model.compute_dtype == torch.float16:     # (fp16 is an inference mode: the statistics pass runs in bf16)
             model.set_compute_dtype(torch.bfloat16)
         model.train()
-        model(x, "train")
+        # (at most 16 x 640^2 pixels of the batch: the training lowering keeps every activation -- 166 GiB for 64 x 1280^2)
+        n_stat = max(1, min(x.shape[0], (16 * 640 * 640) // (x.shape[2] * x.shape[3])))
+        model(x[:n_stat].contiguous(), "train")
     finally:
         for key, v in zip(("_dtype", "_dtype_explicit"), dt_state):
             if v is None:
