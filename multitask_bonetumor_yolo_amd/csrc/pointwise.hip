@@ -86,52 +86,70 @@ template <> __device__ __forceinline__ uint32_t pk16<bf16_t>(float a, float b) {
 template <> __device__ __forceinline__ uint32_t pk16<f16_t>(float a, float b) { return pk_h2(a, b); }
 
 template <int FCH, typename HT>  // Cout / 16; bf16_t or f16_t output
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, float eps, HT* __restrict__ y,
                                                         HT* __restrict__ raw, int N, int H, int W) {
-  typedef typename StemCvt<HT>::vec hvec;
   constexpr int Cout = FCH * 16;
   const int lane = threadIdx.x & 63, nq = lane & 15, q = lane >> 4;
   const int Ho = H >> 2, Wo = W >> 2;
   const long groups = (long)N * Ho * (Wo >> 4);
-  // weight fragments: A[m = ch][k], k = 32 ks + 8 q + j, zero for k >= 48
-  hvec afr[FCH][2];
+  // weight fragments: A[m = ch][k], k = 32 ks + 8 q + j, zero for k >= 48.  Operands are built as PACKED 16-bit pairs (pk16): assembled element
+  // by element as a vector of __bf16, and with no register bound (the compiler hoisted the bias / LayerNorm vectors of all six fragments out of
+  // the loop), the kernel needed 216 registers and ran two waves per SIMD -- a quarter of the waves it takes to cover its load latency: 80 us
+  // for 157 MB (round 3).  Bounded to three waves per SIMD now (four spill 40 registers).
+  uint4 afr[FCH][2];
 #pragma unroll
   for (int f = 0; f < FCH; ++f)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int k0 = ks * 32 + q * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) afr[f][ks][j] = StemCvt<HT>::cv((k0 + j < 48) ? w[(f * 16 + nq) * 48 + k0 + j] : 0.f);
+      const int k0 = ks * 32 + q * 8;                     // (a lane's 8 consecutive k of one weight row: two 16-byte loads, or zeros past k = 48)
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+      if (k0 < 48) { w0 = *reinterpret_cast<const float4*>(w + (f * 16 + nq) * 48 + k0); w1 = *reinterpret_cast<const float4*>(w + (f * 16 + nq) * 48 + k0 + 4); }
+      afr[f][ks] = uint4{pk16<HT>(w0.x, w0.y), pk16<HT>(w0.z, w0.w), pk16<HT>(w1.x, w1.y), pk16<HT>(w1.z, w1.w)};
     }
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  // the image rows of a group are requested one group AHEAD (the wave's next 16 pixels land while it normalises and stores these)
+  float4 pre[2][2];
+  auto fetch = [&](long g) {
+    const int xg = (int)(g % (Wo >> 4));
+    const long ny = g / (Wo >> 4);
+    const int oy = (int)(ny % Ho), n = (int)(ny / Ho);
+    const int ox = xg * 16 + nq;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kc = ks * 4 + q;  // 8-wide k chunk: channel kc/2, kernel rows 2*(kc&1), +1
+      pre[ks][0] = pre[ks][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kc < 6) {
+        const float* src = x + (((long)n * 3 + (kc >> 1)) * H + (oy * 4 + (kc & 1) * 2)) * W + ox * 4;
+        pre[ks][0] = *reinterpret_cast<const float4*>(src);
+        pre[ks][1] = *reinterpret_cast<const float4*>(src + W);
+      }
+    }
+  };
+  if (wave_id < groups) fetch(wave_id);
   for (long g = wave_id; g < groups; g += nwaves) {
     const int xg = (int)(g % (Wo >> 4));
     const long ny = g / (Wo >> 4);
     const int oy = (int)(ny % Ho), n = (int)(ny / Ho);
     const int ox = xg * 16 + nq;
-    hvec bfr[2];
+    uint4 bfr[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int kc = ks * 4 + q;  // 8-wide k chunk: channel kc/2, kernel rows 2*(kc&1), +1
-      if (kc < 6) {
-        const float* src = x + (((long)n * 3 + (kc >> 1)) * H + (oy * 4 + (kc & 1) * 2)) * W + ox * 4;
-        const float4 r0 = *reinterpret_cast<const float4*>(src), r1 = *reinterpret_cast<const float4*>(src + W);
-        bfr[ks][0] = StemCvt<HT>::cv(r0.x); bfr[ks][1] = StemCvt<HT>::cv(r0.y); bfr[ks][2] = StemCvt<HT>::cv(r0.z); bfr[ks][3] = StemCvt<HT>::cv(r0.w);
-        bfr[ks][4] = StemCvt<HT>::cv(r1.x); bfr[ks][5] = StemCvt<HT>::cv(r1.y); bfr[ks][6] = StemCvt<HT>::cv(r1.z); bfr[ks][7] = StemCvt<HT>::cv(r1.w);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bfr[ks][j] = StemCvt<HT>::cv(0.f);
-      }
+      const float4 r0 = pre[ks][0], r1 = pre[ks][1];
+      bfr[ks] = uint4{pk16<HT>(r0.x, r0.y), pk16<HT>(r0.z, r0.w), pk16<HT>(r1.x, r1.y), pk16<HT>(r1.z, r1.w)};
     }
+    if (g + nwaves < groups) fetch(g + nwaves);
+    // (compiler barrier: without it the bias / LayerNorm vectors of all six fragments -- loop-invariant loads -- are hoisted out of the loop, 72
+    //  registers that the allocator then SPILLS to fit four waves per SIMD; read per group they are L1 hits)
+    asm volatile("" ::: "memory");
     f32x4 acc[FCH];
     float s = 0.f;
 #pragma unroll
     for (int f = 0; f < FCH; ++f) {
       acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[f] = mfma_16x16x32<HT>(__builtin_bit_cast(uint4, afr[f][0]), __builtin_bit_cast(uint4, bfr[0]), acc[f]);
-      acc[f] = mfma_16x16x32<HT>(__builtin_bit_cast(uint4, afr[f][1]), __builtin_bit_cast(uint4, bfr[1]), acc[f]);
+      acc[f] = mfma_16x16x32<HT>(afr[f][0], bfr[0], acc[f]);
+      acc[f] = mfma_16x16x32<HT>(afr[f][1], bfr[1], acc[f]);
       const float4 bv = *reinterpret_cast<const float4*>(bias + f * 16 + q * 4);
       acc[f][0] += bv.x; acc[f][1] += bv.y; acc[f][2] += bv.z; acc[f][3] += bv.w;
       s += (acc[f][0] + acc[f][1]) + (acc[f][2] + acc[f][3]);
