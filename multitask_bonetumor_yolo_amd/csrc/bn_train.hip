@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   const long total = pixels * CH8;
   if constexpr (FIXED) {
     const int cg = threadIdx.x % CH8;
+    const int sh = 31 - __builtin_clz(CH8);              // CH8 is a power of two here: pixel = piece >> sh (a 64-bit division per piece otherwise)
     float mu[8], rs[8], ga[8], be[8];
     ld8<float>(mean + cg * 8, mu);
     ld8<float>(var + cg * 8, rs);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       for (int u = 0; u < 4; ++u) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[u][e] = act_apply((v[u][e] - mu[e]) * rs[e] * ga[e] + be[e], ACT < 0 ? act : ACT);
-        st8<T>(y + ((i + u * stride) / CH8) * y_ld + cg * 8, v[u]);
+        st8<T>(y + ((i + u * stride) >> sh) * y_ld + cg * 8, v[u]);
       }
     }
     for (; i < total; i += stride) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       ld8<T>(x + i * 8, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = act_apply((v[e] - mu[e]) * rs[e] * ga[e] + be[e], ACT < 0 ? act : ACT);
-      st8<T>(y + (i / CH8) * y_ld + cg * 8, v);
+      st8<T>(y + (i >> sh) * y_ld + cg * 8, v);
     }
     return;
   }

@@ -173,6 +173,15 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return 1.f;
 }
 
+// v = q * d + r for an element / piece index v that fits 32 bits (every tensor of this library: the entry points refuse more than 2^32 - 1
+// pieces).  `long` quotients compile to 64-bit divisions of ~100 instructions each; four of them per 16-byte piece made index arithmetic the
+// bound of several "HBM-bound" kernels (round 3).
+__device__ __forceinline__ void divmod_u32(long v, int d, long& q, int& r) {
+  const unsigned u = (unsigned)v, qq = u / (unsigned)d;
+  q = (long)qq;
+  r = (int)(u - qq * (unsigned)d);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

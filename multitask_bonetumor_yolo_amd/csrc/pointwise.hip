@@ -429,12 +429,12 @@ __global__ void fuse_kernel(const FuseP p) {
   const int CH8 = p.C >> 3;
   const long total = (long)p.N * p.H * p.W * CH8;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int chunk = (int)(idx % CH8);
-    const long pix = idx / CH8;
-    const int x = (int)(pix % p.W);
-    const long ny = pix / p.W;
-    const int y = (int)(ny % p.H);
-    const int n = (int)(ny / p.H);
+    int chunk, x, y;
+    long pix, ny, nn;
+    divmod_u32(idx, CH8, pix, chunk);
+    divmod_u32(pix, p.W, ny, x);
+    divmod_u32(ny, p.H, nn, y);
+    const int n = (int)nn;
     float acc[8], t[8];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -611,6 +611,7 @@ extern "C" int mtbt_bifpn_fuse(const mtbt_fuse_args* a, void* stream) {
   p.wgt_dev = a->wgt_dev;
   p.n_in = a->n_in; p.y = a->y; p.N = a->N; p.H = a->H; p.W = a->W; p.C = a->C; p.bug = a->add_weight_bug;
   const long total = (long)a->N * a->H * a->W * (a->C / 8);
+  if (total > 0xffffffffL) return MTBT_EINVAL;          // (32-bit piece indices in the kernel)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == MTBT_F32) hipLaunchKernelGGL((fuse_kernel<float>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);
   else if (a->dtype == MTBT_BF16) hipLaunchKernelGGL((fuse_kernel<bf16_t>), dim3(grid_for(total, 256)), dim3(256), 0, s, p);

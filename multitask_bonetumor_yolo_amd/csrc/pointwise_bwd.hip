@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void channel_affine2_kernel(const T* __restric
   const int chunks = C >> 3;
   const long n8 = P * chunks;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-    const int ch = (int)(i % chunks);
+    const int ch = (int)((unsigned)i % (unsigned)chunks);
     float u[8], v[8];
     ld8(x1 + i * 8, u);
     ld8(x2 + i * 8, v);
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
   constexpr int NHX = (IW * IW * PARTS + 255) / 256, NDY = (TS * TS * PARTS + 255) / 256;
   uint4 hx[NHX], hd[NDY];
   auto fetch = [&](long tl) {
-    const int tx = (int)(tl % tiles_x), ty = (int)((tl / tiles_x) % tiles_y), n = (int)(tl / ((long)tiles_x * tiles_y));
+    const unsigned utl = (unsigned)tl;                     // (32-bit tile arithmetic: ntiles < 2^31)
+    const int n = (int)(utl / (unsigned)(tiles_x * tiles_y)), trem = (int)(utl - (unsigned)n * (unsigned)(tiles_x * tiles_y));
+    const int ty = (int)((unsigned)trem / (unsigned)tiles_x), tx = trem - ty * tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
 #pragma unroll
     for (int k = 0; k < NHX; ++k) {                         // halo: zeros outside the image / past the chunk's channels

@@ -41,11 +41,12 @@ __global__ __launch_bounds__(256) void fuse_bwd_dx(const T* __restrict__ dy, T* 
   const long total = (long)N * Hi * Wi * CH8;
   const float wv = *wgt;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int chunk = (int)(idx % CH8);
-    const long pix = idx / CH8;
-    const int x = (int)(pix % Wi);
-    const long ny = pix / Wi;
-    const int y = (int)(ny % Hi), n = (int)(ny / Hi);
+    int chunk, x, y;
+    long pix, ny, nn;
+    divmod_u32(idx, CH8, pix, chunk);
+    divmod_u32(pix, Wi, ny, x);
+    divmod_u32(ny, Hi, nn, y);
+    const int n = (int)nn;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t[8];
     const T* dyn = dy + (long)n * H * W * C + chunk * 8;
     if (mode == 0) {
@@ -124,11 +125,12 @@ __global__ __launch_bounds__(256) void fuse_bwd_dot(const T* __restrict__ dy, co
   const long total = (long)N * H * W * CH8;
   float s = 0.f;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int chunk = (int)(idx % CH8);
-    const long pix = idx / CH8;
-    const int x = (int)(pix % W);
-    const long ny = pix / W;
-    const int y = (int)(ny % H), n = (int)(ny / H);
+    int chunk, x, y;
+    long pix, ny, nn;
+    divmod_u32(idx, CH8, pix, chunk);
+    divmod_u32(pix, W, ny, x);
+    divmod_u32(ny, H, nn, y);
+    const int n = (int)nn;
     float t[8], g[8];
     fetch_resampled<T>(xin, mode, n, y, x, H, W, C, chunk * 8, t);
     ld8<T>(dy + pix * C + chunk * 8, g);
@@ -237,6 +239,7 @@ extern "C" int mtbt_bifpn_fuse_backward(const void* dy, const void* x_in, int mo
   if (dwgt && (!x_in || !workspace || workspace_bytes < mtbt_bifpn_fuse_backward_workspace_bytes())) return MTBT_EWORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int Hi = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wi = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
+  if ((long)N * (Hi > H ? Hi : H) * (Wi > W ? Wi : W) * (C / 8) > 0xffffffffL) return MTBT_EINVAL;   // (32-bit piece indices in the kernels)
   if (dx) {
     const unsigned g = grid_cap((long)N * Hi * Wi * (C / 8), 256);
     if (dtype == MTBT_F32) hipLaunchKernelGGL(fuse_bwd_dx<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (float*)dx, wgt, mode, N, H, W, C, accumulate_dx);

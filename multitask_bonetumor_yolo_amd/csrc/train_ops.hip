@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, in
   const float invM = 1.0f / (float)P;
   if constexpr (FIXED) {
     const int ch = threadIdx.x % chunks;
+    const int sh = 31 - __builtin_clz(chunks);           // chunks is a power of two here: pixel = piece >> sh (a 64-bit division per piece otherwise)
     const BnChan k = bn_chan(mean, var, gamma, beta, eps, ch * 8);
     float m1[8], m2[8], gr[8];
     if (use_running) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, in
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long idx = i + u * stride;
-        ld8<T>(dy + (idx / chunks) * dy_ld + ch * 8, a[u]);
+        ld8<T>(dy + (idx >> sh) * dy_ld + ch * 8, a[u]);
         ld8<T>(x + idx * 8, b[u]);
       }
 #pragma unroll
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ dy, in
     }
     for (; i < n8; i += stride) {
       float a[8], b[8];
-      ld8<T>(dy + (i / chunks) * dy_ld + ch * 8, a);
+      ld8<T>(dy + (i >> sh) * dy_ld + ch * 8, a);
       ld8<T>(x + i * 8, b);
       one(a, b, i);
     }
@@ -373,9 +374,11 @@ template <typename S, typename D>
 __global__ void copy_strided_kernel(const S* __restrict__ src, long sbs, int sld, D* __restrict__ dst, long dbs, int dld, int N, long P, int C, int Cpad) {
   const long total = (long)N * P * Cpad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Cpad);
-    const long np = i / Cpad;
-    const long p = np % P, n = np / P;
+    int c, pi;
+    long np, n;
+    divmod_u32(i, Cpad, np, c);
+    divmod_u32(np, (int)P, n, pi);
+    const long p = pi;
     const float v = c < C ? ld_elem<S>(src + n * sbs + p * sld + c) : 0.f;
     st_elem<D>(dst + n * dbs + p * dld + c, v);
   }
@@ -438,9 +441,11 @@ __global__ __launch_bounds__(256) void add_kernel(T* __restrict__ dst, long dbs,
   const int chunks = C >> 3;
   const long total = (long)N * P * chunks;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int ch = (int)(i % chunks);
-    const long np = i / chunks;
-    const long p = np % P, n = np / P;
+    int ch, pi;
+    long np, n;
+    divmod_u32(i, chunks, np, ch);
+    divmod_u32(np, (int)P, n, pi);
+    const long p = pi;
     float a[8], b[8];
     ld8<T>(dst + n * dbs + p * dld + ch * 8, a);
     ld8<T>(src + n * sbs + p * sld + ch * 8, b);
@@ -543,6 +548,7 @@ extern "C" int mtbt_gap_fc_backward(const void* x, const float* dlogits, const f
 extern "C" int mtbt_copy_strided(const void* src, int src_dtype, int64_t src_batch_stride, int32_t src_pixel_stride, void* dst, int dst_dtype,
                                  int64_t dst_batch_stride, int32_t dst_pixel_stride, int N, int64_t pixels, int C, int C_pad, void* stream) {
   if (!src || !dst || N <= 0 || pixels <= 0 || C <= 0 || C_pad < C || src_pixel_stride < C || dst_pixel_stride < C_pad) return MTBT_EINVAL;
+  if (pixels > 0x7fffffffL || (long)N * pixels * C_pad > 0xffffffffL) return MTBT_EINVAL;   // (32-bit element indices in the kernel)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned g = grid_cap((long)N * pixels * C_pad, 256);
 #define CS(S, D) hipLaunchKernelGGL((copy_strided_kernel<S, D>), dim3(g), dim3(256), 0, s, (const S*)src, (long)src_batch_stride, src_pixel_stride, (D*)dst, \
@@ -576,6 +582,7 @@ extern "C" int mtbt_add_nhwc(void* dst, int64_t dst_batch_stride, int32_t dst_pi
   if (!dst || !src || N <= 0 || pixels <= 0 || C <= 0 || C % 8 || dst_pixel_stride % 8 || src_pixel_stride % 8 || dst_batch_stride % 8 || src_batch_stride % 8)
     return MTBT_EINVAL;
   if (!aligned16(dst) || !aligned16(src)) return MTBT_EALIGN;
+  if (pixels > 0x7fffffffL || (long)N * pixels * (C / 8) > 0xffffffffL) return MTBT_EINVAL;   // (32-bit piece indices in the kernel)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned g = grid_cap((long)N * pixels * (C / 8), 256);
   if (dtype == MTBT_F32)

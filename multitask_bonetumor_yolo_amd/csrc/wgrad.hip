@@ -36,6 +36,7 @@ struct WgP {
   long P, per;        // pixels, pixels per slice (multiple of TPX)
   int nsplit, ktiles, ctiles;
   int xcd_slices;     // slices grouped by XCD (see the kernel)
+  int flat;           // 1 x 1 / stride 1 / pad 0 with dense batch strides: operand rows are indexed by the pixel number
 };
 
 __device__ __forceinline__ s16x4 tr_read(const bf16_t* p) {
@@ -76,7 +77,7 @@ __device__ __forceinline__ uint4 gelu8_bf16(uint4 v) { return uint4{gelu2_bf16(v
 // XACT: the X operand is a PRE-activation and GELU (the bf16 forward's polynomial form) is applied while it is staged -- the fc2 weight gradient of a
 // ConvNeXt block whose fused forward never wrote the activated hidden tensor (mtbt_convnext_mlp_fused_train).
 // WK: waves along the output channels (2: 256 threads; 4: 512 threads, the 256 x 256 tile of the widest GEMM-shaped layers -- each wave still 64 x 128)
-template <bool BIAS, int NK, int NC, bool XACT = false, int WK = 2>   // BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
+template <bool BIAS, int NK, int NC, bool XACT = false, int WK = 2, bool FLAT = false>   // FLAT: operand rows indexed by the pixel number (below); BIAS: also sum dY over the pixels (compiled out of the plain kernel: its registers and branch cost ~8 % there)
 __global__ __launch_bounds__(128 * WK, 2) void wgrad_kernel(const WgP p) {
   constexpr int TKt = TK * NK, TCt = TCH * NC, FA = 8 * NK / WK, FB = 4 * NC;
   constexpr int RP = 8 * WK, LPT = TPX / RP;            // tile rows staged per pass, passes per step (shadows the file-scope LPT of the 256-thread form)
@@ -135,8 +136,22 @@ __global__ __launch_bounds__(128 * WK, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
       for (int h = 0; h < NC; ++h) vx[h][i] = uint4{0u, 0u, 0u, 0u};
       if (pix < p1) {
-        const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
-        const int y = rem / p.Wo, xx = rem - y * p.Wo;
+        if constexpr (FLAT) {   // 1 x 1, stride 1, dense batch strides: pixel index = row of both operands (no divisions: the general path costs
+                        // two 32-bit divisions per piece -- and cost two 64-BIT ones, ~100 instructions each, until round 3)
+          const bf16_t* dyp = p.dy + pix * p.ldy;
+          const bf16_t* xp = p.x + pix * p.ldx;
+#pragma unroll
+          for (int h = 0; h < NK; ++h)
+            if (kch + h * 128 < p.K) vdy[h][i] = *reinterpret_cast<const uint4*>(dyp + kch + h * 128);
+#pragma unroll
+          for (int h = 0; h < NC; ++h)
+            if (cch + h * 128 < p.C) vx[h][i] = *reinterpret_cast<const uint4*>(xp + cch + h * 128);
+          continue;
+        }
+        if constexpr (FLAT) continue;                            // (unreachable: keeps the general addressing out of the FLAT instances)
+        const unsigned upix = (unsigned)pix;                     // (P < 2^31: checked on the host)
+        const int n = (int)(upix / (unsigned)HW), rem = (int)(upix - (unsigned)n * (unsigned)HW);
+        const int y = (int)((unsigned)rem / (unsigned)p.Wo), xx = rem - y * p.Wo;
         const bf16_t* dyp = p.dy + (long)n * p.dy_bs + (long)rem * p.ldy;
 #pragma unroll
         for (int h = 0; h < NK; ++h)
@@ -309,7 +324,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3P p) {
   const long t0 = (long)split * p.per, t1 = min(p.ntiles, t0 + p.per);
   uint4 vdy[2], vx[4];
   auto fetch = [&](long tl) {   // this thread's 16-byte pieces of spatial tile tl (zeros outside the image / past K, C)
-    const int tx = (int)(tl % tiles_x), ty = (int)((tl / tiles_x) % tiles_y), n = (int)(tl / ((long)tiles_x * tiles_y));
+    const unsigned utl = (unsigned)tl;                  // (ntiles < 2^31: 32-bit divisions; the 64-bit ones were ~300 instructions per tile)
+    const int n = (int)(utl / (unsigned)(tiles_x * tiles_y)), trem = (int)(utl - (unsigned)n * (unsigned)(tiles_x * tiles_y));
+    const int ty = (int)((unsigned)trem / (unsigned)tiles_x), tx = trem - ty * tiles_x;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                      // dY tile: 64 pixels x 8 pieces of 8 channels
       const int it = u * 256 + tid, pix = it >> 3, part = it & 7;
@@ -502,8 +519,9 @@ __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float* __restrict
       const long gp = base + pix;
       vi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gp < total) {
-        const int n = (int)(gp / (Ho * Wo));
-        const int rem = (int)(gp - (long)n * Ho * Wo);
+        const unsigned ugp = (unsigned)gp;                 // (total < 2^31: 32-bit divisions)
+        const int n = (int)(ugp / (unsigned)(Ho * Wo));
+        const int rem = (int)(ugp - (unsigned)n * (unsigned)(Ho * Wo));
         const int oy = rem / Wo, ox = rem - oy * Wo;
         vi[u] = *reinterpret_cast<const float4*>(img + (((long)n * 3 + (cky >> 2)) * H + (oy * 4 + (cky & 3))) * W + ox * 4);
       }
@@ -676,22 +694,30 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
   pick_wide(K, C, dbias == nullptr, &nk, &nc);
   p.ktiles = (K + TK * nk - 1) / (TK * nk); p.ctiles = (C + TCH * nc - 1) / (TCH * nc);
   p.xcd_slices = MTBT_WGRAD_XCD_SLICES && p.nsplit >= 8;
+  p.flat = (R == 1 && S == 1 && stride == 1 && pad == 0 && x_batch_stride == (int64_t)H * W * x_pixel_stride &&
+            dy_batch_stride == (int64_t)Ho * Wo * dy_pixel_stride) ? 1 : 0;
+  if (P > 0x7fffffffL) return MTBT_EINVAL;
   const long blocks = (long)(p.xcd_slices ? (p.nsplit + 7) / 8 * 8 : p.nsplit) * R * S * p.ktiles * p.ctiles;
   if (blocks > 0x7fffffffL) return MTBT_EINVAL;
-#define WG(B_)                                                                                                       \
-  do {                                                                                                               \
-    if (nk == 2 && nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 2, false, 4>), dim3((unsigned)blocks), dim3(512), 0, st, p); \
-    else if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);          \
-    else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<B_, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, p);     \
-    else hipLaunchKernelGGL((wgrad_kernel<B_, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);                  \
+#define WGK(B_, NK_, NC_, X_, WK_)                                                                                            \
+  do {                                                                                                                        \
+    if (p.flat) hipLaunchKernelGGL((wgrad_kernel<B_, NK_, NC_, X_, WK_, true>), dim3((unsigned)blocks), dim3(128 * WK_), 0, st, p);  \
+    else hipLaunchKernelGGL((wgrad_kernel<B_, NK_, NC_, X_, WK_, false>), dim3((unsigned)blocks), dim3(128 * WK_), 0, st, p);        \
   } while (0)
-  if (x_act == MTBT_ACT_GELU_POLY) {
-    if (nk == 2 && nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 2, true, 4>), dim3((unsigned)blocks), dim3(512), 0, st, p);
-    else if (nk == 2) hipLaunchKernelGGL((wgrad_kernel<false, 2, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else if (nc == 2) hipLaunchKernelGGL((wgrad_kernel<false, 1, 2, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wgrad_kernel<false, 1, 1, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  } else if (dbias) WG(true); else WG(false);
+#define WGN(B_, NK_, NC_, X_, WK_) hipLaunchKernelGGL((wgrad_kernel<B_, NK_, NC_, X_, WK_, false>), dim3((unsigned)blocks), dim3(128 * WK_), 0, st, p)
+#define WG(B_, X_)                                                  \
+  do {                                                              \
+    if (nk == 2 && nc == 2) WGK(false, 2, 2, X_, 4);                \
+    else if (nk == 2) WGK(B_, 2, 1, X_, 2);                         \
+    else if (nc == 2) WGN(B_, 1, 2, X_, 2);   /* (the flat form of this shape spills 56 registers) */ \
+    else WGK(B_, 1, 1, X_, 2);                                      \
+  } while (0)
+  if (x_act == MTBT_ACT_GELU_POLY) WG(false, true);
+  else if (dbias) WGK(true, 1, 1, false, 2);
+  else WG(false, false);
 #undef WG
+#undef WGN
+#undef WGK
   launch_wgrad_reduce(p.partial, dw, n, p.nsplit, accumulate, st);
   if (dbias) launch_wgrad_reduce(bpartial, dbias, (long)K, p.nsplit, accumulate, st);
   MTBT_LAUNCH_CHECK();
