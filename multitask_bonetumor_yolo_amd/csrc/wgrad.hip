@@ -295,7 +295,7 @@ __device__ __forceinline__ int halo_off(int hp, int col) {   // element offset o
   return hp * 128 + (((col >> 4) ^ key) << 4) + (col & 15);
 }
 
-__global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3P p) {
+__global__ __launch_bounds__(512, 2) void wgrad3x3_halo_kernel(const Wg3P p) {
   __shared__ __attribute__((aligned(16))) bf16_t sdy[64 * 128];
   __shared__ __attribute__((aligned(16))) bf16_t sx[100 * 128];
   int b = blockIdx.x, split;
@@ -310,33 +310,40 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3P p) {
   }
   const int ct = b % p.ctiles;
   const int kt = b / p.ctiles;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // EIGHT waves: the 2 x 2 wave tiles of the 64 x 64 channel tile, twice -- waves 0-3 accumulate taps 0..4, waves 4-7 taps 5..8.  With all
+  // nine taps per wave (144 accumulator registers + addressing) the kernel ran ONE wave per SIMD, four per CU, and sat at ~10 % MFMA
+  // utilisation waiting for its own tile loads; forcing two waves per SIMD on that form spilled into the MFMA loop (1.7 -> 2.9 ms on Proto
+  // cv2).  Split by taps a wave holds 80 accumulators, eight waves fit a CU, and the staging is spread over 512 threads.
+  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
+  const int wave = w8 & 3, tg = w8 >> 2;
   const int wk = wave & 1, wc = wave >> 1;
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const int tiles_x = p.W >> 3, tiles_y = p.H >> 3;
-  f32x4 acc[9][2][2];
+  constexpr int NT = 5;                                  // taps of a wave: tap0 .. tap0 + nt - 1, tap0 = 5 tg, nt = 5 or 4
+  const int tap0 = tg * NT;
+  f32x4 acc[NT][2][2];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long t0 = (long)split * p.per, t1 = min(p.ntiles, t0 + p.per);
-  uint4 vdy[2], vx[4];
+  uint4 vdy[1], vx[2];
   auto fetch = [&](long tl) {   // this thread's 16-byte pieces of spatial tile tl (zeros outside the image / past K, C)
     const unsigned utl = (unsigned)tl;                  // (ntiles < 2^31: 32-bit divisions; the 64-bit ones were ~300 instructions per tile)
     const int n = (int)(utl / (unsigned)(tiles_x * tiles_y)), trem = (int)(utl - (unsigned)n * (unsigned)(tiles_x * tiles_y));
     const int ty = (int)((unsigned)trem / (unsigned)tiles_x), tx = trem - ty * tiles_x;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {                      // dY tile: 64 pixels x 8 pieces of 8 channels
-      const int it = u * 256 + tid, pix = it >> 3, part = it & 7;
+    for (int u = 0; u < 1; ++u) {                      // dY tile: 64 pixels x 8 pieces of 8 channels
+      const int it = u * 512 + tid, pix = it >> 3, part = it & 7;
       const int oy = ty * 8 + (pix >> 3), ox = tx * 8 + (pix & 7), kch = kt * 64 + part * 8;
       vdy[u] = uint4{0u, 0u, 0u, 0u};
       if (kch < p.K) vdy[u] = *reinterpret_cast<const uint4*>(p.dy + (long)n * p.dy_bs + ((long)oy * p.W + ox) * p.ldy + kch);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                      // input halo: 100 pixels x 8 pieces
-      const int it = u * 256 + tid;
+    for (int u = 0; u < 2; ++u) {                      // input halo: 100 pixels x 8 pieces
+      const int it = u * 512 + tid;
       vx[u] = uint4{0u, 0u, 0u, 0u};
       if (it < 800) {
         const int hp = it >> 3, part = it & 7;
@@ -351,13 +358,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3P p) {
   for (long tl = t0; tl < t1; ++tl) {
     __syncthreads();                                   // the previous tile's fragment reads are done
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int it = u * 256 + tid;
+    for (int u = 0; u < 1; ++u) {
+      const int it = u * 512 + tid;
       *reinterpret_cast<uint4*>(sdy + tile_off(it >> 3, (it & 7) * 8)) = vdy[u];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int it = u * 256 + tid;
+    for (int u = 0; u < 2; ++u) {
+      const int it = u * 512 + tid;
       if (it < 800) *reinterpret_cast<uint4*>(sx + halo_off(it >> 3, (it & 7) * 8)) = vx[u];
     }
     __syncthreads();
@@ -374,7 +381,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3P p) {
       }
       const int h_lo = (j_lo >> 3) * 10 + (j_lo & 7);                     // halo pixel of tap (0, 0); tap (r, s) adds r * 10 + s
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = tap0 + tt;                                          // (wave-uniform)
+        if (t >= 9) break;
         const int hl = h_lo + (t / 3) * 10 + (t % 3);
         s16x8 B[2];
 #pragma unroll
@@ -386,22 +395,24 @@ __global__ __launch_bounds__(256) void wgrad3x3_halo_kernel(const Wg3P p) {
         for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
           for (int fb = 0; fb < 2; ++fb)
-            acc[t][fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, B[fb]), acc[t][fa][fb], 0, 0, 0);
+            acc[tt][fa][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[fa]), __builtin_bit_cast(bf16x8, B[fb]), acc[tt][fa][fb], 0, 0, 0);
       }
     }
   }
   const long RSC = 9L * p.C;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb) {
+        const int t = tap0 + tt;
+        if (t >= 9) continue;
         const int c = ct * 64 + 32 * wc + 16 * fb + (lane & 15);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int k = kt * 64 + 32 * wk + 16 * fa + 4 * (lane >> 4) + e;
-          if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)t * p.C + c] = acc[t][fa][fb][e];
+          if (k < p.K && c < p.C) p.partial[((long)split * p.K + k) * RSC + (long)t * p.C + c] = acc[tt][fa][fb][e];
         }
       }
 }
@@ -677,7 +688,7 @@ static int wgrad_entry(const void* x, const void* dy, float* dw, float* dbias, i
     q.xcd_slices = MTBT_WGRAD_XCD_SLICES && ns >= 8;
     const long blocks3 = base * (q.xcd_slices ? (ns + 7) / 8 * 8 : ns);
     if (blocks3 > 0x7fffffffL) return MTBT_EINVAL;
-    hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3((unsigned)blocks3), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(wgrad3x3_halo_kernel, dim3((unsigned)blocks3), dim3(512), 0, st, q);
     launch_wgrad_reduce(q.partial, dw, n, q.nsplit, accumulate, st);
     MTBT_LAUNCH_CHECK();
     return MTBT_OK;
