@@ -78,28 +78,33 @@ template <> __device__ __forceinline__ f32p ld_pair<bf16_t>(const char* p) {
   return f32p{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
 }
 
+// EIGHT waves (round 3): waves 0-3 accumulate the filter rows ky < NKY, waves 4-7 the rest, each group over the same tile rows (wave & 3 owns
+// rows 2w, 2w + 1).  With all KS x KS accumulator pairs per wave (98 registers at 7 x 7, plus the one-tile-ahead staging registers) the
+// kernel ran ONE wave per SIMD -- four per CU -- and its FMAs, LDS reads and load waits had nothing to overlap with.
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
+__global__ __launch_bounds__(512, 2) void dw_wgrad_tile_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int H, int W, int C,
                                                             float* __restrict__ partial /* [slots][(KS*KS + 1) * C]: taps, then sum_p dy */) {
   constexpr int PAD = KS / 2, TS = 8, IW = TS + KS - 1, ES = (int)sizeof(T), PIXB = 128 * ES, EPC = 16 / ES, PARTS = PIXB / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xt = smem;                       // [IW*IW][128] T
   char* dt = smem + IW * IW * PIXB;      // [64][128] T
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NKY = (KS + 1) / 2;                      // filter rows per wave group
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, tg = tid >> 8;
+  const int ky0 = tg * NKY;
   const int chunks = (C + 127) / 128;
   const int chunk = blockIdx.x % chunks, slot = blockIdx.x / chunks, nslots = gridDim.x / chunks;
   const int cb = chunk * 128, cc = min(128, C - cb);
   const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
   const long ntiles = (long)N * tiles_y * tiles_x;
   const bool active = lane * 2 < cc;
-  f32p acc[KS * KS], accb = f32p{0.f, 0.f};
+  f32p acc[NKY * KS], accb = f32p{0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < KS * KS; ++t) acc[t] = f32p{0.f, 0.f};
+  for (int t = 0; t < NKY * KS; ++t) acc[t] = f32p{0.f, 0.f};
   // Staging through REGISTERS, one tile ahead: all of a thread's 16-byte pieces of tile t + 1 (13 of the halo + 4 of dy for 7 x 7 bf16) are
   // requested before the FMAs of tile t and written to LDS behind them.  (Round 3: the first version loaded and stored piece by piece in
   // one loop -- every piece waited for its own round trip, 12 dependent latencies per tile: 24 us per tile where the FMAs need 1.3, 610 us
   // for a stage-0 launch that moves 315 MB.)
-  constexpr int NHX = (IW * IW * PARTS + 255) / 256, NDY = (TS * TS * PARTS + 255) / 256;
+  constexpr int NHX = (IW * IW * PARTS + 511) / 512, NDY = (TS * TS * PARTS + 511) / 512;
   uint4 hx[NHX], hd[NDY];
   auto fetch = [&](long tl) {
     const unsigned utl = (unsigned)tl;                     // (32-bit tile arithmetic: ntiles < 2^31)
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
     const int y0 = ty * TS, x0 = tx * TS;
 #pragma unroll
     for (int k = 0; k < NHX; ++k) {                         // halo: zeros outside the image / past the chunk's channels
-      const int it = tid + k * 256;
+      const int it = tid + k * 512;
       const int pix = it / PARTS, part = it - pix * PARTS;
       const int r = pix / IW, c = pix - r * IW;
       const int iy = y0 + r - PAD, ix = x0 + c - PAD;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
     }
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
-      const int it = tid + k * 256;
+      const int it = tid + k * 512;
       const int pix = it / PARTS, part = it - pix * PARTS;
       const int oy = y0 + pix / TS, ox = x0 + pix % TS;
       hd[k] = uint4{0u, 0u, 0u, 0u};
@@ -131,12 +136,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
     __syncthreads();                                       // the previous tile's readers are done
 #pragma unroll
     for (int k = 0; k < NHX; ++k) {
-      const int it = tid + k * 256;
+      const int it = tid + k * 512;
       if (it < IW * IW * PARTS) *reinterpret_cast<uint4*>(xt + (it / PARTS) * PIXB + (it % PARTS) * 16) = hx[k];
     }
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
-      const int it = tid + k * 256;
+      const int it = tid + k * 512;
       if (it < TS * TS * PARTS) *reinterpret_cast<uint4*>(dt + (it / PARTS) * PIXB + (it % PARTS) * 16) = hd[k];
     }
     __syncthreads();
@@ -147,50 +152,56 @@ __global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(const T* __restrict_
         const int row = 2 * wave + a;
         f32p g[TS];
 #pragma unroll
-        for (int i = 0; i < TS; ++i) { g[i] = ld_pair<T>(dt + (row * TS + i) * PIXB + lane * 2 * ES); accb += g[i]; }   // (bias gradient: sum_p dy)
+        for (int i = 0; i < TS; ++i) { g[i] = ld_pair<T>(dt + (row * TS + i) * PIXB + lane * 2 * ES); accb += g[i]; }   // (bias gradient: sum_p dy; group 0's copy is used)
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
+        for (int kk = 0; kk < NKY; ++kk) {
+          if (ky0 + kk >= KS) break;                        // (wave-uniform: the second group has KS - NKY rows)
           f32p in[IW];
 #pragma unroll
-          for (int j = 0; j < IW; ++j) in[j] = ld_pair<T>(xt + ((row + ky) * IW + j) * PIXB + lane * 2 * ES);
+          for (int j = 0; j < IW; ++j) in[j] = ld_pair<T>(xt + ((row + ky0 + kk) * IW + j) * PIXB + lane * 2 * ES);
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-            for (int i = 0; i < TS; ++i) acc[ky * KS + kx] = __builtin_elementwise_fma(g[i], in[i + kx], acc[ky * KS + kx]);
+            for (int i = 0; i < TS; ++i) acc[kk * KS + kx] = __builtin_elementwise_fma(g[i], in[i + kx], acc[kk * KS + kx]);
         }
       }
     }
   }
-  // fold the four waves of the workgroup through LDS (waves 2, 3 -> 0, 1, then 1 -> 0; a fixed order) so that ONE partial row per
+  // fold the four waves of each group through LDS (waves 2, 3 -> 0, 1, then 1 -> 0; a fixed order) so that ONE partial row per
   // workgroup goes out: the second level reads a quarter of the rows
-  f32p* red = reinterpret_cast<f32p*>(smem);             // [2][KS*KS + 1][64] pairs <= 51 KiB, inside the tile region
-  constexpr int KK1 = KS * KS + 1;
+  f32p* red = reinterpret_cast<f32p*>(smem) + tg * (2 * (NKY * KS + 1) * 64);   // [group][2][NKY*KS + 1][64] pairs <= 59 KiB, inside the tile region
+  constexpr int KK1 = NKY * KS + 1;
   __syncthreads();                                        // the last tile's readers are done
   if (wave >= 2) {
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) red[((wave - 2) * KK1 + t) * 64 + lane] = acc[t];
-    red[((wave - 2) * KK1 + KS * KS) * 64 + lane] = accb;
+    for (int t = 0; t < NKY * KS; ++t) red[((wave - 2) * KK1 + t) * 64 + lane] = acc[t];
+    red[((wave - 2) * KK1 + NKY * KS) * 64 + lane] = accb;
   }
   __syncthreads();
   if (wave < 2) {
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) acc[t] += red[(wave * KK1 + t) * 64 + lane];
-    accb += red[(wave * KK1 + KS * KS) * 64 + lane];
+    for (int t = 0; t < NKY * KS; ++t) acc[t] += red[(wave * KK1 + t) * 64 + lane];
+    accb += red[(wave * KK1 + NKY * KS) * 64 + lane];
   }
   __syncthreads();
   if (wave == 1) {
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) red[t * 64 + lane] = acc[t];
-    red[KS * KS * 64 + lane] = accb;
+    for (int t = 0; t < NKY * KS; ++t) red[t * 64 + lane] = acc[t];
+    red[NKY * KS * 64 + lane] = accb;
   }
   __syncthreads();
   // partial row `slot`: the workgroups of one slot (one per chunk) write disjoint column ranges of the same row, so every row is
   // complete without any zero fill
-  float* dst = partial + (long)slot * KK1 * C;
+  float* dst = partial + (long)slot * (KS * KS + 1) * C;
   if (wave == 0 && active) {
 #pragma unroll
-    for (int t = 0; t < KS * KS; ++t) *reinterpret_cast<f32p*>(dst + (long)t * C + cb + lane * 2) = acc[t] + red[t * 64 + lane];
-    *reinterpret_cast<f32p*>(dst + (long)KS * KS * C + cb + lane * 2) = accb + red[KS * KS * 64 + lane];
+    for (int kk = 0; kk < NKY; ++kk) {
+      if (ky0 + kk >= KS) break;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx)
+        *reinterpret_cast<f32p*>(dst + (long)((ky0 + kk) * KS + kx) * C + cb + lane * 2) = acc[kk * KS + kx] + red[(kk * KS + kx) * 64 + lane];
+    }
+    if (tg == 0) *reinterpret_cast<f32p*>(dst + (long)KS * KS * C + cb + lane * 2) = accb + red[NKY * KS * 64 + lane];
   }
 }
 
@@ -291,7 +302,7 @@ static int dw_wgrad_entry(const void* x, const void* dy, float* dw, float* dbias
 #define DWT(T, KSV)                                                                                                      \
   do {                                                                                                                  \
     if (int rc = mtbt_allow_lds(dw_wgrad_tile_kernel<T, KSV>, lds)) return rc;                                           \
-    hipLaunchKernelGGL((dw_wgrad_tile_kernel<T, KSV>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)dy, (const T*)x, N, H, W, C, partial); \
+    hipLaunchKernelGGL((dw_wgrad_tile_kernel<T, KSV>), dim3((unsigned)blocks), dim3(512), lds, s, (const T*)dy, (const T*)x, N, H, W, C, partial); \
   } while (0)
   if (dtype == MTBT_BF16) { if (ksize == 7) DWT(bf16_t, 7); else DWT(bf16_t, 3); }
   else { if (ksize == 7) DWT(float, 7); else DWT(float, 3); }
