@@ -39,6 +39,9 @@ SHAPES = {
 def bench(shape, hint, dtype=torch.bfloat16, iters=20):
     N, H, W, C, K, k, act, use_res = shape
     N = int(os.environ.get("MTBT_TUNE_BATCH", N))      # (the training step runs the same layers at batch 32)
+    sc_ = int(os.environ.get("MTBT_TUNE_SCALE", "1"))   # configs[4]: the same layers on 1280^2 inputs (maps x 2), batch 64, fp16
+    H, W = H * sc_, W * sc_
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("MTBT_TUNE_DTYPE", "bf16")] if dtype == torch.bfloat16 else dtype
     p = Plan(DEV)
     x = Act.of(torch.randn(N, H, W, C, device=DEV).to(dtype))
     w = (torch.randn(K, k * k * C, device=DEV) / (k * k * C) ** 0.5).to(dtype)
