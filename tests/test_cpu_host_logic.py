@@ -231,3 +231,21 @@ def test_compose_upconv_equals_convtranspose_then_conv3x3():
             out[:, :, a::2, b::2] = acc + s9[cls].permute(2, 0, 1)[None]
     assert (out - ref).abs().max().item() < 2e-4
     assert (s9[4] - s9[0]).abs().max().item() > 1e-3                                # the border classes really differ
+
+
+def test_plan_option_precedence(monkeypatch):
+    """model.plan_options (what GraphedInference(autotune=True) writes) > MTBT_<NAME> > default (model.plan_option)."""
+    from multitask_bonetumor_yolo_amd import model as M
+
+    class Dummy:
+        pass
+    m = Dummy()
+    monkeypatch.delenv("MTBT_SEG_GATE", raising=False)
+    assert M.plan_option(m, "SEG_GATE") == M.PLAN_OPTION_DEFAULTS["SEG_GATE"] == "0"
+    monkeypatch.setenv("MTBT_SEG_GATE", "2")
+    assert M.plan_option(m, "SEG_GATE") == "2"
+    m.plan_options = {"SEG_GATE": "1"}
+    assert M.plan_option(m, "SEG_GATE") == "1"
+    assert M.plan_option(m, "LANES") is None              # scheduler knobs default to "not set" (engine.Plan reads its own defaults)
+    m.plan_options = {"SEG_GATE": None}
+    assert M.plan_option(m, "SEG_GATE") == "2"             # an explicit None falls through to the environment

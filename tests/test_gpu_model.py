@@ -357,6 +357,38 @@ def test_concurrent_lanes_are_deterministic_at_full_size(monkeypatch):
         assert all(torch.equal(a, b) for a, b in zip(ref, snap(g.fwd, g.out)))
 
 
+def test_autotuned_schedule_keeps_the_results():
+    """GraphedInference(autotune=True) times the launch-schedule options on the live machine and keeps the fastest in model.plan_options.  Whatever it
+    picks, the step computes the same thing: with the lowering option NODE_FUSED pinned off (the only one that changes arithmetic, by one bf16 ulp)
+    every output of the tuned graph is BIT-IDENTICAL to the default schedule's; and the candidates are freed as it goes (plans cache empty but for
+    the winner)."""
+    from multitask_bonetumor_yolo_amd import init_synthetic_, graphed
+    from multitask_bonetumor_yolo_amd.graphed import GraphedInference
+    torch.manual_seed(7)
+    hip = init_synthetic_(ConvNeXtBiFPNYOLO(2, 2, pretrained_backbone=False)).to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.rand(4, 3, 256, 256, device=DEV)
+
+    def snap(g):
+        g.replay()
+        torch.cuda.synchronize()
+        return [t.clone() for t in (g.fwd["segment_preds_cat"], g.fwd["detect_preds_cat"], g.fwd["segment_protos"][2], g.fwd["img_cls_logits"],
+                                    g.out["keep_idx"], g.out["masks"])]
+    ref = snap(GraphedInference(hip, x, 256))
+    lines = []
+    knobs = tuple(k for k in graphed.AUTOTUNE_KNOBS if k[0] != "NODE_FUSED")
+    old = graphed.AUTOTUNE_KNOBS
+    graphed.AUTOTUNE_KNOBS = knobs
+    try:
+        g = GraphedInference(hip, x, 256, autotune=True, log=lines.append)
+    finally:
+        graphed.AUTOTUNE_KNOBS = old
+    assert len(lines) == 2 + sum(len(v) for _, v in knobs) and lines[-1].startswith("autotune: kept")
+    assert isinstance(hip.plan_options, dict) and set(hip.plan_options) <= {k for k, _ in knobs}
+    assert len(hip.__dict__.get("_plans", {})) == 1
+    got = snap(g)
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+
+
 def test_graph_outlives_plan_eviction_and_refuses_stale_weights():
     """a captured graph points into its launch plan's buffers and folded weights.  The GraphedInference object keeps that plan
     alive when the model's plan cache drops it, refuses to replay after the weights changed, and a graph can be destroyed and a new one
