@@ -179,7 +179,9 @@ struct EpiSeq { long pix0; int jstep; long npix; long ybias, rbias; };
 // load above the previous, possibly aliasing, store: FP x ITER dependent latencies per tile (round 3: found in the depthwise kernel first,
 // where the same pattern cost 40 % of the input-gradient launches).  Reading everything first is safe under aliasing: a lane reads exactly the
 // locations it writes later, and tiles are disjoint.  Implicit-GEMM kernels only (FP x ITER x 4 registers; the direct kernels have none to spare).
-template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, bool RESPF = false>
+// RESPF = 2: ONE slab ahead instead of the whole tile (ITER x 4 registers): slab j + 1's pieces are requested before slab j is stored -- for the
+// direct 3x3 kernels, which have no room for the whole tile's.
+template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, int RESPF = 0>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase, int chl0, int lane,
                                                    const EpiSeq q, long srow = -1) {
   constexpr int WCH = FC * 16;
@@ -221,8 +223,19 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
   HT* const yp = reinterpret_cast<HT*>(p.y);
   HT* const y2p = reinterpret_cast<HT*>(p.y2);
   const T* const rp = reinterpret_cast<const T*>(p.res);
-  uint4 rpf[RESPF ? FP : 1][RESPF ? ITER : 1];
-  if constexpr (RESPF) {
+  uint4 rpf[RESPF == 1 ? FP : 1][RESPF ? ITER : 1];     // RESPF == 2: one slab's pieces (the NEXT slab's, see the row pass)
+  uint4 rnx[RESPF == 2 ? ITER : 1];
+  auto fetch_res = [&](int j, uint4 (&dst)[RESPF ? ITER : 1]) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      dst[RESPF ? it : 0] = uint4{0u, 0u, 0u, 0u};
+      if (ok[it] && px[it] + (long)j * q.jstep < q.npix) dst[RESPF ? it : 0] = *reinterpret_cast<const uint4*>(rp + ro[it] + j * rstep);
+    }
+  };
+  if constexpr (RESPF == 2) {
+    if (MODE == 2 || has_res) fetch_res(0, rpf[0]);
+  }
+  if constexpr (RESPF == 1) {
     if (MODE == 2 || has_res) {
 #pragma unroll
       for (int j = 0; j < FP; ++j)
@@ -251,6 +264,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
       *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local hand-off through LDS (see the general body)
+    if constexpr (RESPF == 2) {
+      if ((MODE == 2 || has_res) && j + 1 < FP) fetch_res(j + 1, rnx);      // the next slab's residual: in flight across this slab's stores
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       if (!ok[it] || px[it] + (long)j * q.jstep >= q.npix) continue;
@@ -265,12 +281,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
       }
       if (MODE == 2) {
         float r[8];
-        if constexpr (RESPF) ld8<T>(reinterpret_cast<const T*>(&rpf[RESPF ? j : 0][RESPF ? it : 0]), r); else ld8<T>(rp + roff, r);
+        if constexpr (RESPF != 0) ld8<T>(reinterpret_cast<const T*>(&rpf[RESPF == 1 ? j : 0][RESPF ? it : 0]), r); else ld8<T>(rp + roff, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= act_grad(r[e], ACT);
       } else if (has_res) {
         float r[8];
-        if constexpr (RESPF) ld8<T>(reinterpret_cast<const T*>(&rpf[RESPF ? j : 0][RESPF ? it : 0]), r); else ld8<T>(rp + roff, r);
+        if constexpr (RESPF != 0) ld8<T>(reinterpret_cast<const T*>(&rpf[RESPF == 1 ? j : 0][RESPF ? it : 0]), r); else ld8<T>(rp + roff, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += r[e];
       }
@@ -280,13 +296,17 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
         for (int e = 0; e < 8; ++e) { const float d = stored_value<HT>(v[e]) - csh[e]; cs[e] += d; cq[e] += d * d; }
       }
     }
+    if constexpr (RESPF == 2) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) rpf[0][it] = rnx[it];
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
   }
   if constexpr (SUMS && (C8 & (C8 - 1)) == 0) colsum_flush<C8>(p, cs, cq, srow, cs_ch, cs_ch < p.K, lane);
 }
 
 // Dispatcher: ONE switch per call.  `seq` non-null = the caller's output pixels form the arithmetic sequence the fast body wants.
-template <typename T, int TC, int FC, int FP, bool TRAIN = true, bool RESPF = TRAIN, typename AddrFn>
+template <typename T, int TC, int FC, int FP, bool TRAIN = true, int RESPF = (TRAIN ? 1 : 0), typename AddrFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq seq, bool use_seq,
                                               long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {

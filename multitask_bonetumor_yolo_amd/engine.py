@@ -138,6 +138,29 @@ class _Schedule:
 
 
 _LANE_STREAMS = {}
+_RESERVED = {}          # device index -> {role: torch.cuda.Stream}: the process-wide streams of this package, pairwise distinct HIP streams
+
+
+def reserved_stream(device, role: str) -> torch.cuda.Stream:
+    """One process-wide stream per (device, role) whose underlying HIP stream is DISTINCT from every other stream this package reserved.
+    torch.cuda.Stream() hands out a pool of 32 streams round-robin: the 33rd object aliases the first.  A long-lived process (a test session:
+    dozens of GraphedInference objects, two streams each) therefore ended up with a capture stream or the NMS side stream that WAS one of the
+    plan's lane streams -- a fork / join nested below a non-origin stream, which segfaults hipStreamEndCapture on ROCm 7.2 (round 3; tools/
+    capture_topo.py has the topology).  Reserved streams are never destroyed: captured graphs may outlive the objects that recorded them."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    table = _RESERVED.setdefault(idx, {})
+    s = table.get(role)
+    if s is None:
+        taken = {t.cuda_stream for t in table.values()}
+        for _ in range(256):
+            s = torch.cuda.Stream(device=dev)
+            if s.cuda_stream not in taken and s.cuda_stream != 0:
+                break
+        else:
+            raise RuntimeError("no distinct HIP stream left in torch's pool")
+        table[role] = s
+    return s
 
 
 class Plan:
@@ -262,7 +285,7 @@ class Plan:
         # process-wide per device and never destroyed: captured graphs may outlive the plan that recorded them
         cur = _LANE_STREAMS.setdefault(torch.device(self.device).index or 0, [])
         while len(cur) < n:
-            cur.append(torch.cuda.Stream(device=self.device))
+            cur.append(reserved_stream(self.device, f"lane{len(cur) + 1}"))
         return cur[:n]
 
     def dependencies(self):

@@ -25,7 +25,6 @@ class GraphedInference:
         side moves the replay time by +-4 % (a fused kernel that is 15 % faster alone made the step 0.24 ms SLOWER because the prototype
         chain then started later), nothing of which a static cost model sees.  Results do not depend on the schedule."""
         if autotune:
-            import gc
             import time
             opts = dict(model.__dict__.get("plan_options", {}))
 
@@ -44,8 +43,6 @@ class GraphedInference:
                 # batch 64 x 1280^2 -- nine candidates kept alive ran the 288 GB card out of memory, round 3)
                 del g
                 model.__dict__.get("_plans", {}).clear()
-                gc.collect()
-                torch.cuda.empty_cache()
                 return dt
             best = timed(dict(opts))
             if log:
@@ -67,8 +64,10 @@ class GraphedInference:
         self.model, self.x = model, x
         self._compiled = None             # the lowered plan the captured kernels point into: pool buffers + folded weights
         self.args = (img_size, conf_th, iou_th, top_k, masks)
-        self.stream = torch.cuda.Stream(device=x.device)
-        self.side = torch.cuda.Stream(device=x.device)   # decode + NMS fork (see _Base.infer_and_detect)
+        # process-wide capture / side streams, distinct from the plan's lane streams (engine.reserved_stream: why)
+        from .engine import reserved_stream
+        self.stream = reserved_stream(x.device, "graph_capture")
+        self.side = reserved_stream(x.device, "graph_side")   # decode + NMS fork (see _Base.infer_and_detect)
         self.graph = torch.cuda.CUDAGraph()
         self.stream.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(self.stream), torch.no_grad():

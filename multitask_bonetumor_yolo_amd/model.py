@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import Act, Plan, code_of, TORCH_DTYPE
+from .engine import Act, Plan, code_of, TORCH_DTYPE, reserved_stream
 
 BN_MOMENTUM, BN_EPS = 0.9997, 4e-5  # main_model.py:95,135
 LN_EPS = 1e-6                       # timm ConvNeXt [upstream]
@@ -849,7 +849,7 @@ class _Base(nn.Module):
             self._bind_input(c, x)
             maps = c.det_maps if c.det_maps is not None else c.seg_maps
             main = torch.cuda.current_stream(x.device)
-            side = side_stream or self.__dict__.setdefault("_side_stream", torch.cuda.Stream(device=x.device))
+            side = side_stream or reserved_stream(x.device, "eager_side")
             ready = c.plan.run(marks={"det": c.det_marks, "mask": c.mask_marks if masks else []})
             mk = None
             with torch.cuda.stream(side):

@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import code_of
+from .engine import code_of, reserved_stream
 from .loss import multitask_loss
 from .train import TrainPlan, make_arena
 
@@ -118,7 +118,7 @@ class TrainStep:
         self.loss_kw = dict(img_size=self.S, nc_det=model.nc_det, reg_max=model.detect.reg_max, iou_match_thresh=iou_match_thresh,
                             label_smoothing=label_smoothing, training=True, weights=loss_weights)
         # ---- gradient exchange: bucket b is complete once EVERY backward launch in writers[b] has run ----
-        self.comm = torch.cuda.Stream(device=dev) if (self.world > 1 and overlap) else None
+        self.comm = reserved_stream(dev, "grad_exchange") if (self.world > 1 and overlap) else None
         self.writers = bucket_writers(self.bwd.launches, self.grads.buckets)
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -389,6 +389,19 @@ def test_autotuned_schedule_keeps_the_results():
     assert all(torch.equal(a, b) for a, b in zip(ref, got))
 
 
+def test_reserved_streams_are_distinct_hip_streams():
+    """torch.cuda.Stream() cycles through a pool of 32: the 33rd object IS the first.  The plan's lane streams, the graph's capture / side streams
+    and the gradient-exchange stream come from engine.reserved_stream, which keeps them pairwise distinct however many streams the process created
+    before -- an aliased capture stream segfaulted hipStreamEndCapture (a whole test session was enough to get there)."""
+    from multitask_bonetumor_yolo_amd.engine import reserved_stream
+    junk = [torch.cuda.Stream(device=DEV) for _ in range(40)]            # wrap torch's pool
+    roles = ["lane1", "lane2", "lane3", "graph_capture", "graph_side", "eager_side", "grad_exchange", "test_extra"]
+    got = [reserved_stream(DEV, r) for r in roles]
+    assert len({s.cuda_stream for s in got}) == len(roles) and all(s.cuda_stream != 0 for s in got)
+    assert all(reserved_stream(DEV, r) is s for r, s in zip(roles, got))   # one per role, process-wide
+    del junk
+
+
 def test_graph_outlives_plan_eviction_and_refuses_stale_weights():
     """a captured graph points into its launch plan's buffers and folded weights.  The GraphedInference object keeps that plan
     alive when the model's plan cache drops it, refuses to replay after the weights changed, and a graph can be destroyed and a new one
