@@ -88,7 +88,8 @@ def test_dwconv_dgrad(dtype, C, k, H):
                                          (2, 9, 7, 512, 384, 1),      # wide tile on the input channels (128 x 256)
                                          (1, 12, 12, 256, 256, 1),    # square 256: one wide tile per row
                                          (1, 6, 6, 256, 192, 3),      # k x k taps with a wide input side, ragged output-channel tile
-                                         (1, 12, 11, 768, 512, 1)])   # 256 x 256 tile, 512 threads (the stage-3 MLP shapes)
+                                         (1, 12, 11, 768, 512, 1),    # 256 x 256 tile, 512 threads (the stage-3 MLP shapes)
+                                         (2, 16, 24, 96, 160, 3)])    # 3x3 halo kernel (eight waves, taps split 5 + 4) with ragged channel tiles on both sides
 def test_conv_wgrad(N, H, W, C, K, k):
     """Weight gradient (csrc/wgrad.hip) vs autograd, bf16-rounded operands, ragged channel tiles and pixel slices."""
     g = torch.Generator().manual_seed(N * H + K + k)
@@ -255,7 +256,7 @@ def test_layernorm_backward(dtype, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C,k,H", [(96, 7, 18), (256, 3, 11)])
+@pytest.mark.parametrize("C,k,H", [(96, 7, 18), (256, 3, 11), (192, 7, 40), (384, 3, 16)])   # (two chunks x many tiles per slot; three chunks)
 def test_dwconv_wgrad(dtype, C, k, H):
     g = torch.Generator().manual_seed(C * k)
     N = 2
