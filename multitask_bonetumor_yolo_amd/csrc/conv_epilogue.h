@@ -181,7 +181,9 @@ struct EpiSeq { long pix0; int jstep; long npix; long ybias, rbias; };
 // locations it writes later, and tiles are disjoint.  Implicit-GEMM kernels only (FP x ITER x 4 registers; the direct kernels have none to spare).
 // RESPF = 2: ONE slab ahead instead of the whole tile (ITER x 4 registers): slab j + 1's pieces are requested before slab j is stored -- for the
 // direct 3x3 kernels, which have no room for the whole tile's.
-template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, int RESPF = 0>
+// DB: the wave owns TWO slab regions (slab, slab + 16 * PITCH): slab j + 1 is written while slab j is read back, one LDS round trip per slab
+// instead of two (implicit-GEMM kernels: their LDS has the room).
+template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, int RESPF = 0, bool DB = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase, int chl0, int lane,
                                                    const EpiSeq q, long srow = -1) {
   constexpr int WCH = FC * 16;
@@ -246,8 +248,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
         }
     }
   }
-#pragma clang loop unroll(full)
-  for (int j = 0; j < FP; ++j) {
+  constexpr int SLB = 16 * PITCH;
+  auto write_slab = [&](int j, char* sb) {
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
       float4 s4, h4;
@@ -261,9 +263,25 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
       v.x = fmaf(acc[i][j][0], s4.x, h4.x); v.y = fmaf(acc[i][j][1], s4.y, h4.y);
       v.z = fmaf(acc[i][j][2], s4.z, h4.z); v.w = fmaf(acc[i][j][3], s4.w, h4.w);
       if (MODE == 0) { v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT); }
-      *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
+      *reinterpret_cast<float4*>(sb + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local hand-off through LDS (see the general body)
+  };
+  char* const slab0 = slab;
+  if constexpr (DB) write_slab(0, slab0);
+#pragma clang loop unroll(full)
+  for (int j = 0; j < FP; ++j) {
+    slab = slab0 + (DB ? (j & 1) * SLB : 0);
+    if constexpr (DB) {
+      if (j + 1 < FP) {
+        write_slab(j + 1, slab0 + ((j + 1) & 1) * SLB);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FC) : "memory");   // slab j is in LDS (its FC writes are older than the FC just issued)
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
+      write_slab(j, slab);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local hand-off through LDS (see the general body)
+    }
     if constexpr (RESPF == 2) {
       if ((MODE == 2 || has_res) && j + 1 < FP) fetch_res(j + 1, rnx);      // the next slab's residual: in flight across this slab's stores
     }
@@ -300,26 +318,28 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
 #pragma unroll
       for (int it = 0; it < ITER; ++it) rpf[0][it] = rnx[it];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slab fully read before the next pass rewrites it
+    // slab fully read before it is rewritten (DB: the NEXT write goes to the other region; this one is rewritten a pass later, by
+    // which time these reads were consumed -- the barrier below only keeps the compiler from moving that write up)
+    if constexpr (DB) asm volatile("" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   if constexpr (SUMS && (C8 & (C8 - 1)) == 0) colsum_flush<C8>(p, cs, cq, srow, cs_ch, cs_ch < p.K, lane);
 }
 
 // Dispatcher: ONE switch per call.  `seq` non-null = the caller's output pixels form the arithmetic sequence the fast body wants.
-template <typename T, int TC, int FC, int FP, bool TRAIN = true, int RESPF = (TRAIN ? 1 : 0), typename AddrFn>
+template <typename T, int TC, int FC, int FP, bool TRAIN = true, int RESPF = (TRAIN ? 1 : 0), bool DB = false, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq seq, bool use_seq,
                                               long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {
   // (seq by VALUE: behind a conditional pointer the struct was materialised in scratch memory in the fp16 kernels)
-#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, RESPF>(p, acc, slab, aff, cbase, chl0, lane, seq)
+#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, RESPF, DB>(p, acc, slab, aff, cbase, chl0, lane, seq)
   // (fp32 storage always writes fp32: the fast bodies -- 16-bit outputs -- are not even compiled for it)
   const bool fast = sizeof(T) == 2 && use_seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
   constexpr bool CS_OK = (((FC * 16) / 8) & ((FC * 16) / 8 - 1)) == 0;
   if constexpr (sizeof(T) == 2) {
   if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
-    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, RESPF>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, RESPF, DB>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
     // (16-bit storage: the polynomial derivative has the compiled body; MTBT_ACT_DGELU falls through to the general one)
-    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, RESPF>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, RESPF, DB>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
   } else if (fast && !(TRAIN && p.y2)) {
     switch (p.act) {
       case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;
