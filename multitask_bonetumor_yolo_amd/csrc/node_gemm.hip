@@ -63,9 +63,11 @@ __global__ __launch_bounds__(256, 2) void node_gemm_kernel(const NodeP p) {
     const long pix = pix0 + q;
     const bool ok = pix < M;
     const long pc = ok ? pix : M - 1;             // (ragged last tile: fetch a valid pixel, store zeros)
-    const int x = (int)(pc % p.f.W);
-    const long ny = pc / p.f.W;
-    const int y = (int)(ny % p.f.H), n = (int)(ny / p.f.H);
+    int x, y;                                     // (32-bit index arithmetic: M < 2^31 -- as `long` these were 64-bit divisions, ~100 instructions each,
+    long ny, nn;                                  //  sixteen per thread and workgroup)
+    divmod_u32(pc, p.f.W, ny, x);
+    divmod_u32(ny, p.f.H, nn, y);
+    const int n = (int)nn;
     float t0[8], t1[8], t2[8], acc[8];
     fuse_fetch<T>(reinterpret_cast<const T*>(p.f.x[0]), M0, n, y, x, p.f.H, p.f.W, C, c8 * 8, t0);
     fuse_fetch<T>(reinterpret_cast<const T*>(p.f.x[1]), M1, n, y, x, p.f.H, p.f.W, C, c8 * 8, t1);
@@ -126,7 +128,7 @@ template <typename T, int KT, int NIN, int M0, int M1, int M2>
 int launch_node_t(const NodeP& p, hipStream_t s) {
   const long M = (long)p.f.N * p.f.H * p.f.W;
   const long blocks = (M + 63) / 64;
-  if (blocks <= 0 || blocks > 0x7fffffffL) return MTBT_EINVAL;
+  if (blocks <= 0 || blocks > 0x7fffffffL || M > 0x7fffffffL) return MTBT_EINVAL;      // (32-bit pixel indices in the kernel)
   constexpr int lds = 64 * KT * 2 + 2 * KT * 4;
   if (int rc = mtbt_allow_lds(node_gemm_kernel<T, KT, NIN, M0, M1, M2>, lds)) return rc;
   hipLaunchKernelGGL((node_gemm_kernel<T, KT, NIN, M0, M1, M2>), dim3((unsigned)blocks), dim3(256), lds, s, p);

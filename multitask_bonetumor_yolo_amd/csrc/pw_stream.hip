@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const ConvP p) {
     const long pix = pix0 + j * 16 + lr;
     ok[j] = pix < p.M;
     const long pc = ok[j] ? pix : (long)p.M - 1;
-    const long n = pc / HW, r = pc - n * HW;
+    long n;
+    int ri;
+    divmod_u32(pc, HW, n, ri);                    // (M < 2^31)
+    const long r = ri;
     const T* xp = xb + n * p.xbs + r * p.ldx + lq * 8;
     yoff[j] = n * p.ybs + r * p.ldy;
 #pragma unroll
