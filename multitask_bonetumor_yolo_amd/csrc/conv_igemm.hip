@@ -4,7 +4,9 @@
 #include "conv_params.h"
 #include "rowreduce.h"
 
-// per (storage type, K-step width) translation units; two LDS stages (deeper pipelines never paid: residency beats prefetch depth)
+// per (storage type, K-step width) translation units; two LDS stages (deeper pipelines never paid: residency beats prefetch depth -- re-checked in
+// round 3 inside a dependent launch chain with 4 / 6 / 8 stages on 64x64, 128x64, 64x32 and 128x32 tiles: level on the 20x20 maps, 1.5 - 2.5x
+// slower wherever the grid needs the residency; profiles/r03_chain_probe_deep_pipelines.txt)
 #define MTBT_DECL(dt)                                                                      \
   int mtbt_conv_dispatch_##dt##_wide(const ConvP& p, int TC, int TP, hipStream_t s);       \
   int mtbt_conv_dispatch_##dt##_narrow(const ConvP& p, int TC, int TP, hipStream_t s);     \
@@ -28,7 +30,7 @@ int mtbt_pw_stream(const ConvP& p, int dtype, hipStream_t s);
 //     -> 32 KiB of LDS, three or more workgroups per CU hide the load / epilogue latency of the short K loop;
 //   * k x k convolutions (MFMA-bound): 128-pixel tiles with 128-byte K-steps while that still gives >= 2
 //     workgroups per CU, else 64x64 (small pyramid levels, 64-channel head convs).
-static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow, bool no96 = false) {
+static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, int* TP, int* narrow, bool no96 = false, int act = 0) {
   // pol (mtbt_conv_args.policy, a development A/B knob the host passes per call): bit0 = small 1x1 tiles, bit1 = 64x64 for small k x k
   int tc;
   if (K % 128 == 0) tc = 128;
@@ -45,11 +47,30 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
     return;
   }
   if (taps == 1 && (pol & 1)) {
-    // round-2 sweep (profiles/r02_f_conv_tune_1x1.txt, after the epilogue was split by activation): 128x128 tiles once the grid holds >= 4 of
-    // them per CU (fc1 of every stage, the C2f 1x1s at P3: 6-18 % faster than 128x64), 128x64 below that; 64-byte K-steps for short rows
+    // Round 3, re-measured IN A DEPENDENT CHAIN (tools/chain_tune.py, profiles/r03_chain_tune.txt: 32 launches in one captured graph, operands
+    // out of the Infinity Cache as behind a producer).  The round-2 rules came from an eager same-buffer loop that is host-bound below ~15 us
+    // and L2-warm, and had it backwards on the small maps:
+    //   * 128-byte K-steps wherever the row allows (they never lose; 64-byte steps only for rows that are not a multiple of 128 bytes);
+    //   * what decides the tile is the ROUND structure on the 512 workgroup slots (256 CUs x 2): 300 - 512 workgroups of the largest tile
+    //     that gives that many -- one full round -- beat twice as many half tiles (256 -> 256 @40x40: 128x128 11.3 us, 128x64 14.3;
+    //     512 -> 256 @40x40: 15.8 against 21.5) and 513 - 1023 is the worst place to be (a second, mostly empty round: 384 -> 384 @40x40);
+    //   * 64-channel and narrower outputs (the heads): 64-pixel tiles at every level.
+    const bool can_wide = (C * es) % 128 == 0;
+    *narrow = can_wide ? 0 : 1;
+    if (tc == 128) {
+      const long g = ((M + 127) / 128) * ct, g2 = ((M + 63) / 64) * ct, g4 = ((M + 63) / 64) * ((K + 63) / 64);
+      *TC = 128;
+      if (g >= 1024) *TP = (act == MTBT_ACT_ELU && g < 4096) ? 64 : 128;      // (the ELU epilogue is long: BiFPN pointwise @80x80 49.9 against 58.7 us)
+      else if (g >= 300 && g <= 512) *TP = 128;
+      else if (g > 512 || (g2 >= 300 && g2 <= 512)) *TP = 64;
+      else if (K % 64 == 0 && g4 <= 1024) { *TC = 64; *TP = 64; }
+      else *TP = 64;
+      return;
+    }
     *TC = tc;
-    *TP = (tc != 128 || ((M + 127) / 128) * ct >= 1024) ? 128 : 64;
-    *narrow = (C * es <= (tc != 128 ? 1536 : (*TP == 128 ? 1024 : 512))) ? 1 : 0;
+    if (tc <= 64) { *TP = 64; return; }
+    *TP = 128;
+    *narrow = (C * es <= 1536 || !can_wide) ? 1 : 0;
     return;
   }
   *narrow = 0;
@@ -60,7 +81,9 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
   }
   if (K <= 64) { *TC = K > 32 ? 64 : 32; *TP = 64; return; }
   // (round-2 sweep, profiles/r02_f_conv_tune_3x3.txt: one 128-pixel tile per CU is already enough -- c2f_p4.m 3x3 192->192 @40: 40.3 -> 31.6 us)
-  if (((M + 127) / 128) * ct >= 256) { *TC = tc; *TP = 128; return; }
+  const long gk = ((M + 127) / 128) * ct;
+  if (gk > 512 && gk < 1024 && tc == 128) { *TC = tc; *TP = 64; return; }   // (chain sweep: a second, mostly empty round of 128x128 tiles -- stage-2 downsample 38.1 -> 33.9 us)
+  if (gk >= 256) { *TC = tc; *TP = 128; return; }
   if (((M + 63) / 64) * ct >= 256) { *TC = tc; *TP = 64; return; }
   *TC = (tc == 96) ? 96 : 64;
   *TP = 64;
@@ -178,7 +201,7 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
   int TC, TP, nbuf = 0;
   if (a->tile_hint) { nbuf = (a->tile_hint >> 28) & 7; TC = (a->tile_hint >> 16) & 0x1ff; TP = a->tile_hint & 0xffff; }
   int narrow = (a->tile_hint >> 27) & 1;  // hint bit 27: force 64-byte K-steps
-  if (!a->tile_hint || !TC || !TP) pick_tile(pol, a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow, want_cs);
+  if (!a->tile_hint || !TC || !TP) pick_tile(pol, a->K, p.M, a->R * a->S, a->C, es, &TC, &TP, &narrow, want_cs, a->act);
   if (want_cs && TC == 96) return MTBT_EINVAL;   // (a wave's 48 / 96 channels are not a power-of-two number of 8-channel pieces)
   const int wide = (a->C % (128 / es) == 0 && !narrow) ? 1 : 0;
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));

@@ -29,7 +29,13 @@ struct MaskX4P {
   float* logits;
   unsigned char* masks;
   int tiles_x, tiles_y;
+  int dbg;   // development ablation bits (tools/probes/mask_variants.hip; compiled in only with -DMTBT_MASK_ABLATION)
 };
+#ifdef MTBT_MASK_ABLATION
+#define MASK_ABL(p, bit) ((p).dbg & (bit))
+#else
+#define MASK_ABL(p, bit) 0
+#endif
 
 constexpr int NM = 32;          // prototype channels
 constexpr int PPITCH = NM + 1;  // patch row pitch (floats): conflict-free column reads
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
   for (int i = tid; i < NPXP * (NM / 4); i += 256) {
     const int px = i >> 3, c4 = i & 7;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (px < NPX) {
+    if (px < NPX && !MASK_ABL(p, 8)) {
       const int py = px / PW, pxx = px - py * PW;
       const int ly = min(max(ly_base + py, 0), p.hp - 1), lx = min(max(lx_base + pxx, 0), p.wp - 1);
       v = *reinterpret_cast<const float4*>(pr + ((long)ly * p.wp + lx) * NM + c4 * 4);
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
       float a[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) a[ks] = coef[(lane & 15) * PPITCH + ks * 4 + (lane >> 4)];
-      for (int pg = wave; pg < NPXP / 16; pg += 4) {
+      for (int pg = wave; pg < NPXP / 16 && !MASK_ABL(p, 4); pg += 4) {
         f32x4 acc = f32x4{p.bias, p.bias, p.bias, p.bias};
         const float* bp = patch + (pg * 16 + (lane & 15)) * PPITCH + (lane >> 4);
 #pragma unroll
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
     }
     __syncthreads();
     // 2c. x4 bilinear + threshold, 16 pixels per thread per box
-    if (oy < p.Hout) {
+    if (oy < p.Hout && !MASK_ABL(p, 2)) {
       const int nb = min(16, cnt - g0);
       for (int b = 0; b < nb; ++b) {
         const float* r0 = low + b * LPITCH + iy * PW + seg * 4;
@@ -131,18 +137,34 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
           // 6 columns x 2 + 16 pixels x 2 multiply-adds instead of 16 x 6 -- and the threshold + byte packing is one FMA and one
           // v_cvt_pk_u8_f32 per pixel: (v - 2^-24) * 2^100 saturates to 255 above the threshold and to 0 at or below it.  The value
           // differs from torch's horizontal-first association in the last bits only: the mask can differ where |logit| ~ 1e-7.
+          // Vertical taps first (6 columns), then per PIXEL PAIR two packed FMAs that produce the thresholding value directly:
+          //   d = (wx0 2^100) v[ix] + (wx1 2^100) v[ix + 1] - 2^76      (an even pixel and its right neighbour share ix)
+          // d saturates to 255 above the threshold 2^-24 and to 0 at or below it in v_cvt_pk_u8_f32: 2 vector operations per pixel instead of 4.
+          typedef float f2 __attribute__((ext_vector_type(2)));
           float v[6];
 #pragma unroll
           for (int c = 0; c < 6; ++c) v[c] = wy0 * t0[c] + wy1 * t1[c];
           unsigned w[4] = {0u, 0u, 0u, 0u};
+          if (MASK_ABL(p, 16)) {   // ablation: the scalar form (one multiply-add chain and one conversion per pixel)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int ix = (e + 2) >> 2;                                   // compile-time
-            const float wx1 = ((e + 2) & 3) * 0.25f + 0.125f, wx0 = 1.0f - wx1;
-            const float val = wx0 * v[ix] + wx1 * v[ix + 1];
-            w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(val, 0x1p100f, -0x1p76f), e & 3, w[e >> 2]);
+            for (int e = 0; e < 16; ++e) {
+              const int ix = (e + 2) >> 2;
+              const float wx1 = ((e + 2) & 3) * 0.25f + 0.125f, wx0 = 1.0f - wx1;
+              const float val = wx0 * v[ix] + wx1 * v[ix + 1];
+              w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(val, 0x1p100f, -0x1p76f), e & 3, w[e >> 2]);
+            }
+          } else
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const int ix = (e + 2) >> 2;                                   // compile-time; the same for e and e + 1
+            const float a1 = ((e + 2) & 3) * 0.25f + 0.125f, b1 = ((e + 3) & 3) * 0.25f + 0.125f;
+            const f2 W1 = f2{a1 * 0x1p100f, b1 * 0x1p100f}, W0 = f2{(1.0f - a1) * 0x1p100f, (1.0f - b1) * 0x1p100f};
+            f2 d = __builtin_elementwise_fma(W0, f2{v[ix], v[ix]}, f2{-0x1p76f, -0x1p76f});
+            d = __builtin_elementwise_fma(W1, f2{v[ix + 1], v[ix + 1]}, d);
+            w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(d.x, e & 3, w[e >> 2]);
+            w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(d.y, (e + 1) & 3, w[e >> 2]);
           }
-          *reinterpret_cast<uint4*>(p.masks + obase_m) = uint4{w[0] & 0x01010101u, w[1] & 0x01010101u, w[2] & 0x01010101u, w[3] & 0x01010101u};
+          if (!MASK_ABL(p, 1) || (w[0] ^ w[1] ^ w[2] ^ w[3]) == 0x12345679u) *reinterpret_cast<uint4*>(p.masks + obase_m) = uint4{w[0] & 0x01010101u, w[1] & 0x01010101u, w[2] & 0x01010101u, w[3] & 0x01010101u};
           continue;
         }
         float o[16];
@@ -203,5 +225,6 @@ int mtbt_mask_x4_try(const mtbt_mask_args* a, hipStream_t stream) {
   p.gather = a->gather_idx; p.counts = a->counts; p.bias = a->bias;
   p.N = a->N; p.K = a->K; p.hp = a->hp; p.wp = a->wp; p.Hout = a->Hout; p.Wout = a->Wout;
   p.logits = a->logits; p.masks = a->masks;
+  p.dbg = 0;
   return a->Wout % 128 == 0 ? launch_mask_x4<32, 8>(p, a, stream) : launch_mask_x4<16, 16>(p, a, stream);
 }

@@ -120,7 +120,8 @@ int launch_t(const ConvP& p, hipStream_t s) {
 // Whether mtbt_conv2d_nhwc hands this call to the streaming kernel (conv_igemm.hip asks before it picks a tile).  `vec_ok` of p = 16-byte
 // fp32 stores are whole and aligned (pixel / batch stride multiples of 4 elements, aligned base): set by the caller.
 bool mtbt_pw_stream_applies(const ConvP& p, int dtype) {
-  return (dtype == MTBT_BF16 || dtype == MTBT_F16) && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && (p.C == 32 || p.C == 64 || p.C == 128 || p.C == 256) && p.K <= 64 &&
+  return (dtype == MTBT_BF16 || dtype == MTBT_F16) && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && (p.C == 32 || p.C == 64) && p.K <= 32 &&   // (wider shapes: the 64-pixel implicit-GEMM tiles are 15 - 25 % faster in a launch chain, profiles/r03_chain_tune.txt)
+        
          p.out_f32 && p.out_mode == MTBT_OUT_NHWC && p.act == MTBT_ACT_NONE && !p.scale && !p.res && !p.y2 && !p.cs_part && !p.debug;
 }
 
