@@ -55,7 +55,7 @@ extern "C" {
 
 /* Bumped whenever an argument struct or a signature below changes (round 1 = 1; round 2 added fields / positional arguments without
  * bumping it; round 3 starts at 3).  The library travels prebuilt: a binding built against another header must refuse to load. */
-#define MTBT_ABI_VERSION 4
+#define MTBT_ABI_VERSION 5
 int mtbt_abi_version(void);
 /* sizeof() of the argument structs as the LIBRARY was compiled: which = 0 mtbt_conv_args, 1 mtbt_fuse_args, 2 mtbt_decode_args,
  * 3 mtbt_mask_args, 4 mtbt_loss_args, 5 mtbt_prep_desc, 6 mtbt_raw_image, 7 mtbt_upconv_args, 8 mtbt_node_args; -1 for any other value.  A binding compares them with its
@@ -562,6 +562,18 @@ int64_t mtbt_bifpn_fuse_backward_workspace_bytes(void);
 int mtbt_bifpn_fuse_backward(const void* dy, const void* x_in, int mode, const float* wgt, void* dx, int accumulate_dx, float* dwgt,
                              int accumulate_dwgt, int N, int H, int W, int C, int dtype, void* workspace, int64_t workspace_bytes,
                              void* stream);
+
+/* The oldest variant's WeightedAdd node (reference src/model.py:27-37: `w = relu(w); w = w / (w.sum() + eps); sum(w_i + f_i)`; its inputs
+ * src/model.py:60-74: identity, F.interpolate(scale_factor=2, mode="nearest"), F.max_pool2d(., 2)), training side:
+ *   mtbt_wadd_norm_weights            out[i] = relu(w[i]) / (sum_j relu(w[j]) + eps), n <= 8 (the forward fusion reads them through wgt_dev)
+ *   mtbt_wadd_norm_weights_backward   dw[j] (+)= [w[j] > 0] * eps / (s + eps)^2 * sum(dy); dy_colsum [C] = per-channel sums of dy
+ *   mtbt_resample_backward            dx (+)= resample^T(dy) for ONE input: mode 0 identity, 3 nearest x2 up (x_in / dx [N,H/2,W/2,C]),
+ *                                     4 max pooling 2x2 (x_in / dx [N,2H,2W,C]; x_in = the forward input, required: dy goes to each window's
+ *                                     first maximum in row-major order, as torch's max_pool2d backward does).  Dense NHWC, f32 / bf16. */
+int mtbt_wadd_norm_weights(const float* w, int n, float eps, float* out, void* stream);
+int mtbt_wadd_norm_weights_backward(const float* w, int n, float eps, const float* dy_colsum, int C, float* dw, int accumulate, void* stream);
+int mtbt_resample_backward(const void* dy, const void* x_in, int mode, void* dx, int accumulate, int N, int H, int W, int C, int dtype,
+                           void* stream);
 
 /* Backward of the trainer's proto projector + bilinear resize (running_main_v3.py:251-255): dseg [N,Hout,Wout] f32 = d loss / d (resized
  * logits); protos [N,hp,wp,nm] f32 (forward output); w [nm] the Conv2d(nm,1,1) weight.  d_protos [N,hp,wp,nm] (dprotos_dtype) (+)=;

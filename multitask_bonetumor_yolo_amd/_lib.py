@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmtbt_hip.so")
 
-ABI_VERSION = 4          # include/mtbt_hip.h MTBT_ABI_VERSION
+ABI_VERSION = 5          # include/mtbt_hip.h MTBT_ABI_VERSION
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_ELU, ACT_GELU, ACT_GELU_POLY, ACT_DSILU, ACT_DELU, ACT_DGELU, ACT_DGELU_POLY = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OUT_NHWC, OUT_CONVT2X2 = 0, 1
@@ -168,6 +168,9 @@ SYMBOLS = {
     "mtbt_weight_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mtbt_bifpn_norm_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mtbt_bifpn_norm_weights_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mtbt_wadd_norm_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "mtbt_wadd_norm_weights_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mtbt_resample_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p]),
     "mtbt_bifpn_fuse_backward_workspace_bytes": (C.c_int64, []),
     "mtbt_bifpn_fuse_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5
                                  + [C.c_void_p, C.c_int64, C.c_void_p]),

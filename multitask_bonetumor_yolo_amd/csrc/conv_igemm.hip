@@ -20,7 +20,7 @@ MTBT_DECL(f32)
 MTBT_DECL(f16)
 #undef MTBT_DECL
 // pw_stream.hip: the heads' output 1x1 convolutions (few input channels, <= 64 outputs, fp32 strided store) without LDS
-bool mtbt_pw_stream_applies(const ConvP& p, int dtype);
+bool mtbt_pw_stream_applies(const ConvP& p, int dtype, bool any_width);
 int mtbt_pw_stream(const ConvP& p, int dtype, hipStream_t s);
 
 // Tile heuristics, from the sweep in tools/conv_tune.py on the shapes of the 640x640 batch-16 forward
@@ -178,7 +178,7 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // narrow 1x1 convolutions into an fp32 map (the heads' output convs): streaming kernel, same arithmetic (a tile hint keeps the call on
   // the implicit-GEMM kernel: tests, A/B)
-  if (!a->tile_hint && !layout && (pol & 64) == 0 && (long)a->K * a->C * es < 0x7fff0000L && mtbt_pw_stream_applies(p, a->dtype)) return mtbt_pw_stream(p, a->dtype, s);
+  if (!a->tile_hint && !layout && (pol & 64) == 0 && (long)a->K * a->C * es < 0x7fff0000L && mtbt_pw_stream_applies(p, a->dtype, (pol & 128) != 0)) return mtbt_pw_stream(p, a->dtype, s);
   // 3x3 / stride 1 / pad 1 on 16-aligned maps: direct convolution with an LDS-resident halo tile (conv3x3_direct.inc).
   // tile_hint bit 26 (or MTBT_CONV_POLICY bit 2 cleared) keeps such a conv on the implicit-GEMM kernel (tests, A/B).
   {

@@ -3,6 +3,9 @@
 //                              dx_i (+)= w_i * resample_i^T(dy)   and   dw_i = <dy, resample_i(x_i)>
 //   mtbt_projector_backward    the trainer's proto projector + bilinear resize (running_main_v3.py:251-255) behind the seg BCE:
 //                              d_low = bilinear^T(d seg logits), d protos = w (x) d_low, d w = <d_low, protos>, d b = sum d_low
+//   mtbt_resample_backward     one input of the oldest variant's WeightedAdd node y = sum_i (w_i + resample_i(x_i)) (src/model.py:27-37, 60-74):
+//                              dx_i (+)= resample_i^T(dy) for identity, nearest x2 (F.interpolate) and 2x2 max pooling (F.max_pool2d)
+//   mtbt_wadd_norm_weights(_backward)  that node's weights relu(w) / (sum relu(w) + eps) on the device, and d w from sum(dy)
 // The transposes are written in GATHER form: an input pixel visits the output pixels whose forward footprint can contain it and
 // re-evaluates the forward's own index / weight arithmetic, so forward and backward agree by construction (borders included).
 #include "common.h"
@@ -222,6 +225,85 @@ __global__ void proj_bwd_w_out(const float* __restrict__ sums, int nm, float* __
   if (c == nm && db) *db = accumulate ? *db + sums[nm] : sums[nm];
 }
 
+// src/model.py variant: thread = (input pixel, 8-channel chunk).  mode 0 identity; 3 nearest x2 up (input [N,H/2,W/2,C]: the transpose sums
+// the 2x2 block of dy); 4 max pooling 2x2 / 2 (input [N,2H,2W,C]: dy goes to the window's FIRST maximum in row-major order, torch's choice
+// -- `val > maxval` while scanning -- and every other position gets zero).
+template <typename T>
+__global__ __launch_bounds__(256) void resample_bwd_dx(const T* __restrict__ dy, const T* __restrict__ xin, T* __restrict__ dx, int mode, int N, int H, int W,
+                                                       int C, int accumulate) {
+  const int CH8 = C >> 3;
+  const int Hi = mode == 3 ? H >> 1 : (mode == 4 ? H << 1 : H), Wi = mode == 3 ? W >> 1 : (mode == 4 ? W << 1 : W);
+  const long total = (long)N * Hi * Wi * CH8;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    int chunk, x, y;
+    long pix, ny, nn;
+    divmod_u32(idx, CH8, pix, chunk);
+    divmod_u32(pix, Wi, ny, x);
+    divmod_u32(ny, Hi, nn, y);
+    const int n = (int)nn;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t[8];
+    const T* dyn = dy + (long)n * H * W * C + chunk * 8;
+    if (mode == 0) {
+      ld8<T>(dyn + ((long)y * W + x) * C, acc);
+    } else if (mode == 3) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          ld8<T>(dyn + ((long)(2 * y + a) * W + (2 * x + b)) * C, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += t[e];
+        }
+    } else {
+      const int wy = y & ~1, wx = x & ~1, me = (y & 1) * 2 + (x & 1);
+      const T* xn = xin + (long)n * Hi * Wi * C + chunk * 8;
+      float best[8];
+      int arg[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ld8<T>(xn + ((long)(wy + (k >> 1)) * Wi + (wx + (k & 1))) * C, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k == 0 || t[e] > best[e] || t[e] != t[e]) { best[e] = t[e]; arg[e] = k; }
+      }
+      ld8<T>(dyn + ((long)(y >> 1) * W + (x >> 1)) * C, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = arg[e] == me ? t[e] : 0.f;
+    }
+    T* dst = dx + pix * C + chunk * 8;
+    if (accumulate) {
+      ld8<T>(dst, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += t[e];
+    }
+    st8<T>(dst, acc);
+  }
+}
+
+// WeightedAdd of src/model.py:27-37: w~ = relu(w) / (sum relu(w) + eps); the node ADDS sum_i w~_i = s / (s + eps) to every element.
+__global__ void wadd_norm_kernel(const float* __restrict__ w, int n, float eps, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += fmaxf(w[i], 0.f);
+  for (int i = 0; i < n; ++i) out[i] = fmaxf(w[i], 0.f) / (s + eps);
+}
+// d w_j (+)= [w_j > 0] * eps / (s + eps)^2 * sum(dy): `colsum` = the per-channel sums of dy (mtbt_channel_sum), folded here in a fixed order
+__global__ __launch_bounds__(64) void wadd_norm_bwd_kernel(const float* __restrict__ w, int n, float eps, const float* __restrict__ colsum, int C, float* __restrict__ dw,
+                                                           int accumulate) {
+  float t = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) t += colsum[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += fmaxf(w[i], 0.f);
+  const float g = eps / ((s + eps) * (s + eps)) * t;
+  for (int i = 0; i < n; ++i) {
+    const float v = w[i] > 0.f ? g : 0.f;
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t mtbt_bifpn_fuse_backward_workspace_bytes(void) { return 1024 * (int64_t)sizeof(float); }
@@ -290,6 +372,39 @@ extern "C" int mtbt_projector_backward(const float* dseg, const float* protos, c
     hipLaunchKernelGGL(channel_sum_final, dim3((unsigned)((cols + 3) / 4)), dim3(256), 0, s, partial, (int)blocks, cols, sums, 0);
     hipLaunchKernelGGL(proj_bwd_w_out, dim3(1), dim3(256), 0, s, sums, nm, dw, db, accumulate_dw);
   }
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+
+// One input of a WeightedAdd node of the src/model.py variant.  dy [N,H,W,C] (the node's output gradient); x_in (mode 4 only: the forward input,
+// needed to find each window's maximum) / dx: [N,H,W,C] (mode 0), [N,H/2,W/2,C] (mode 3, nearest x2) or [N,2H,2W,C] (mode 4, max pooling 2x2).
+extern "C" int mtbt_resample_backward(const void* dy, const void* x_in, int mode, void* dx, int accumulate, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || (mode != 0 && mode != 3 && mode != 4)) return MTBT_EINVAL;
+  if (mode == 3 && ((H & 1) || (W & 1))) return MTBT_EINVAL;
+  if (mode == 4 && !x_in) return MTBT_EINVAL;
+  if (dtype != MTBT_F32 && dtype != MTBT_BF16) return MTBT_EINVAL;
+  if (!aligned16(dy) || !aligned16(dx) || (x_in && !aligned16(x_in))) return MTBT_EALIGN;
+  const int Hi = mode == 3 ? H / 2 : (mode == 4 ? H * 2 : H), Wi = mode == 3 ? W / 2 : (mode == 4 ? W * 2 : W);
+  if ((long)N * (Hi > H ? Hi : H) * (Wi > W ? Wi : W) * (C / 8) > 0xffffffffL) return MTBT_EINVAL;   // (32-bit piece indices in the kernel)
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned g = grid_cap((long)N * Hi * Wi * (C / 8), 256);
+  if (dtype == MTBT_F32) hipLaunchKernelGGL(resample_bwd_dx<float>, dim3(g), dim3(256), 0, s, (const float*)dy, (const float*)x_in, (float*)dx, mode, N, H, W, C, accumulate);
+  else hipLaunchKernelGGL(resample_bwd_dx<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x_in, (bf16_t*)dx, mode, N, H, W, C, accumulate);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_wadd_norm_weights(const float* w, int n, float eps, float* out, void* stream) {
+  if (!w || !out || n <= 0 || n > 8) return MTBT_EINVAL;
+  hipLaunchKernelGGL(wadd_norm_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), w, n, eps, out);
+  MTBT_LAUNCH_CHECK();
+  return MTBT_OK;
+}
+
+extern "C" int mtbt_wadd_norm_weights_backward(const float* w, int n, float eps, const float* dy_colsum, int C, float* dw, int accumulate, void* stream) {
+  if (!w || !dy_colsum || !dw || n <= 0 || n > 8 || C <= 0) return MTBT_EINVAL;
+  hipLaunchKernelGGL(wadd_norm_bwd_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), w, n, eps, dy_colsum, C, dw, accumulate);
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

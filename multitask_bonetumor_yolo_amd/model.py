@@ -1037,9 +1037,11 @@ class _BackboneV0(_Params):
 class ConvNeXtBiFPNYOLOv0(_Base):
     """Oldest variant, `/root/reference/src/model.py:97-123` (BASELINE config 0): ConvNeXt-T features -> BiFPN with
     lateral Convs / nearest-x2 / max-pool / DWConv 3x3 nodes and the weight-ADDING WeightedAdd ->
-    Detect + Segment + cls.  `forward(x, mode="infer")` does not touch the heads' training flags; this build lowers the
-    eval state (module.eval()), i.e. `{"detect": (y, feats), "segment": (cat[y, mc], (feats, mc, protos)), "img_cls": softmax}`
-    or, for any other mode, the raw `(det_out, seg_out, logits)` tuple."""
+    Detect + Segment + cls.  Unlike the later variants its `forward` does not touch the heads' training flags: the heads answer in
+    whatever mode the module is in.  `module.eval()`: `{"detect": (y, feats), "segment": (cat[y, mc], (feats, mc, protos)), "img_cls":
+    softmax}` or, for any other mode string, the raw `(det_out, seg_out, logits)` tuple.  `module.train()` (both heads in training mode):
+    the training lowering (train.py: batch-statistic BatchNorm, autograd node, backward plan) with the heads' training outputs --
+    `det_out` = the three raw maps, `seg_out` = (maps, mc, protos).  One head in each mode is not lowered."""
 
     def __init__(self, nc_det: int, nc_img: int, proto_ch: int = 32):
         super().__init__()
@@ -1051,10 +1053,20 @@ class ConvNeXtBiFPNYOLOv0(_Base):
         self.segment = Segment(nc_det, nm=proto_ch, ch=ch)
         self.cls_pool = nn.AdaptiveAvgPool2d(1)
         self.cls_fc = nn.Linear(256, nc_img)
+        self.nc_det, self.nc_img, self.proto_ch = nc_det, nc_img, proto_ch
 
     def forward(self, x, mode: str = "infer"):
-        if self.detect.training or self.segment.training or any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
-            raise NotImplementedError("the src/model.py variant is lowered for module.eval() only")
+        if self.detect.training != self.segment.training:
+            raise NotImplementedError("the src/model.py variant is lowered with both heads in the same mode (module.train() or module.eval())")
+        if self.detect.training:          # src/model.py:105-123 under module.train(): Detect returns its maps, Segment (maps, mc, protos)
+            from .train import train_forward
+            det, seg, mc, protos, logits = train_forward(self, x)
+            det_out, seg_out = det, (seg, mc, protos)
+            if mode == "infer":
+                return {"detect": det_out, "segment": (seg_out[0], seg_out[1]), "img_cls": logits.softmax(1)}
+            return det_out, seg_out, logits
+        if any(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
+            raise NotImplementedError("the src/model.py variant: eval-mode heads over train-mode BatchNorm layers are not lowered")
         c = self._run(x)
         det_feats = [m.nchw().clone() for m in c.det_maps]
         seg_feats = [m.nchw().clone() for m in c.seg_maps]

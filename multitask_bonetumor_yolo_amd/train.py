@@ -863,6 +863,56 @@ class TrainPlan:
             p3, p4, p5 = p3_td, p4_out, p5_out
         return p3, p4, p5
 
+    # -- neck of the oldest variant (src/model.py:27-93): lateral Convs, WeightedAdd (ADDS its normalised weights), DWConv 3x3 nodes --
+    def neck_v0(self, f3, f4, f5):
+        nk = self.m.neck
+        p3 = self.conv_bn_act(f3, nk.lat3, None, L.ACT_SILU, "neck.lat3")
+        p4 = self.conv_bn_act(f4, nk.lat4, None, L.ACT_SILU, "neck.lat4")
+        p5 = self.conv_bn_act(f5, nk.lat5, None, L.ACT_SILU, "neck.lat5")
+        for ui, u in enumerate(nk.units):
+            nm = f"neck.units.{ui}"
+
+            def node(add, inputs, modes, like: Act, key, nm=nm, u=u):
+                # y = sum_i (w~_i + resample_i(x_i)), w~ = relu(w) / (sum relu(w) + eps): the weights are parameters, normalised on the device
+                n = len(inputs)
+                w = _dense_vec(add.w, f"{nm}.add_{key}.w")
+                wn = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self.fwd.raw(self.lib.mtbt_wadd_norm_weights, (w.data_ptr(), n, C.c_float(add.eps), wn.data_ptr()), f"{nm}.add_{key}.norm", keep=(w, wn),
+                             reads=[w], writes=[wn])
+                s_ = self.new(like.N, like.H, like.W, like.C)
+                a = self.fwd.fuse(inputs, [0.0] * n, modes, s_, bug=True, name=f"{nm}.add_{key}")
+                a.wgt_dev = wn.data_ptr()
+                self.fwd.launches[-1].keep += (wn,)
+                self.fwd.launches[-1].reads += (_region(wn),)
+
+                def bwd():
+                    if not self.has_grad(s_):
+                        return
+                    ds = self.G(s_)
+                    # d w: the node adds s / (s + eps) to EVERY element, so d w_j = [w_j > 0] eps / (s + eps)^2 sum(dy)
+                    cs = torch.zeros(s_.C, dtype=torch.float32, device=self.device)
+                    self.bwd.channel_sum(ds, cs, name=f"{nm}.add_{key}.dysum")
+                    gw = self.pg(add.w)
+                    self.bwd.raw(self.lib.mtbt_wadd_norm_weights_backward, (w.data_ptr(), n, C.c_float(add.eps), cs.data_ptr(), s_.C, gw.data_ptr(), 0),
+                                 f"{nm}.add_{key}.norm.bwd", keep=(w, cs, gw), reads=[w, cs], writes=[gw])
+                    for i, (xin, mode) in enumerate(zip(inputs, modes)):
+                        gx = self.G(xin)
+                        acc = self.acc(xin)
+                        args = (ds.ptr, xin.ptr, mode, gx.ptr, int(acc), s_.N, s_.H, s_.W, s_.C, self.code)
+                        self.bwd.raw(self.lib.mtbt_resample_backward, args, f"{nm}.add_{key}.bwd{i}", keep=(ds.buf, xin.buf, gx.buf),
+                                     reads=[ds, xin] + ([gx] if acc else []), writes=[gx])
+                        self.bwd.est(2.0 * s_.N * s_.H * s_.W * s_.C * ESIZE[self.code])
+                    self.done(s_)
+                self.tape.append(bwd)
+                return self.dw_bn_act(s_, u.conv[key], f"{nm}.conv.{key}")
+
+            p4_td = node(u.add_p4_td, [p4, p5], [L.RES_ID, L.RES_UP_NEAREST], p4, "p4_td")
+            p3_td = node(u.add_p3_td, [p3, p4_td], [L.RES_ID, L.RES_UP_NEAREST], p3, "p3_td")
+            p4_out = node(u.add_p4_out, [p4, p4_td, p3_td], [L.RES_ID, L.RES_ID, L.RES_MAXPOOL], p4, "p4_out")
+            p5_out = node(u.add_p5_out, [p5, p4_out], [L.RES_ID, L.RES_MAXPOOL], p5, "p5_out")
+            p3, p4, p5 = p3_td, p4_out, p5_out
+        return p3, p4, p5
+
     # -- heads [ultralytics Detect / Segment / Proto] --
     def _f32(self, *shape) -> torch.Tensor:
         return torch.zeros(shape, dtype=torch.float32, device=self.device)
@@ -1004,10 +1054,13 @@ class TrainPlan:
         m = self.m
         bb = m.backbone
         f3, f4, f5 = self.features(bb.body)
-        c3 = self.c2f(f3, bb.c2f_p3, "backbone.c2f_p3")
-        c4 = self.c2f(f4, bb.c2f_p4, "backbone.c2f_p4")
-        c5 = self.c2f(f5, bb.c2f_p5, "backbone.c2f_p5")
-        n3, n4, n5 = self.neck(c3, c4, c5)
+        if hasattr(bb, "c2f_p3"):
+            c3 = self.c2f(f3, bb.c2f_p3, "backbone.c2f_p3")
+            c4 = self.c2f(f4, bb.c2f_p4, "backbone.c2f_p4")
+            c5 = self.c2f(f5, bb.c2f_p5, "backbone.c2f_p5")
+            n3, n4, n5 = self.neck(c3, c4, c5)
+        else:                       # the src/model.py variant: no adaptors, its own neck
+            n3, n4, n5 = self.neck_v0(f3, f4, f5)
         feats = [n3, n4, n5]
         self.det_maps = self.det_branch(feats, m.detect, "detect", "det") if hasattr(m, "detect") else None
         self.seg_maps = self.det_branch(feats, m.segment, "segment", "seg")

@@ -153,6 +153,7 @@ def test_head_output_conv_streams(dtype, cfg):
         ybuf = torch.full((N, rows, pitch), 7.0, dtype=torch.float32, device=DEV)
         ya = Act(ybuf, c0, N, H, W, K, pitch, rows * pitch)
         p = Plan(torch.device(DEV))
+        p.conv_policy = 0x100 | 7 | 128      # policy bit 7: the streaming kernel takes every shape it can run (by default only the narrow ones: round 3)
         p.conv(Act.of(nhwc(x).to(dtype)), w.reshape(K, Cin).contiguous().to(DEV, dtype), ya, R=1, S=1, shift=b.to(DEV), tile_hint=hint)
         run(p)
         outs.append(ybuf.clone())

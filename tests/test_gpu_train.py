@@ -89,6 +89,53 @@ def test_every_parameter_gradient_matches_autograd_fp32(variant):
             assert (hb[name].cpu() - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-3), name
 
 
+def test_src_model_py_variant_trains_fp32():
+    """BASELINE config 0's graph (reference src/model.py:97-123) under module.train(): lateral Convs, the weight-ADDING WeightedAdd nodes over
+    identity / nearest-x2 / max-pooled inputs, DWConv 3x3 + BatchNorm + SiLU, the heads' training outputs.  Forward and EVERY parameter
+    gradient (the WeightedAdd weights included: one of them negative, relu' = 0) against autograd through the oracle."""
+    from multitask_bonetumor_yolo_amd import ConvNeXtBiFPNYOLOv0
+    from oracle.model import ConvNeXtBiFPNYOLOv0 as OModelV0
+    torch.manual_seed(3)
+    ora = randomize_(OModelV0(2, 2), 3)
+    with torch.no_grad():
+        for ui, u in enumerate(ora.neck.units):
+            u.add_p4_td.w.copy_(torch.tensor([0.7, 1.3]) + 0.1 * ui)
+            u.add_p3_td.w.copy_(torch.tensor([1.5, 0.4]))
+            u.add_p4_out.w.copy_(torch.tensor([1.2, -0.3, 0.8]))
+            u.add_p5_out.w.copy_(torch.tensor([0.9, 1.1]))
+    hip = ConvNeXtBiFPNYOLOv0(2, 2)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    ora.train()
+    hip.train()
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 128, 128, generator=g)
+    ro = flat_outputs(ora(x, "train"))
+    ho = flat_outputs(hip(x.to(DEV), "train"))
+    worst = 0.0
+    for r, h in zip(ro, ho):
+        assert tuple(r.shape) == tuple(h.shape)
+        worst = max(worst, (h.detach().float().cpu() - r.detach()).abs().max().item())
+    assert worst < 1e-3, f"train-mode forward of the src/model.py variant differs from the oracle by {worst}"
+    probes = [torch.randn(r.shape, generator=g) / r[0].numel() ** 0.5 for r in ro]
+    sum((r * w).sum() for r, w in zip(ro, probes)).backward()
+    sum((h * w.to(DEV)).sum() for h, w in zip(ho, probes)).backward()
+    torch.cuda.synchronize()
+    compare_grads(ora, hip, 1e-3, "src/model.py variant fp32")
+    hb = dict(hip.named_buffers())
+    for name, b in ora.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(hb[name]) == int(b), name
+        elif name.endswith("running_mean") or name.endswith("running_var"):
+            assert (hb[name].cpu() - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-3), name
+    # the dict form of the same call, and the mixed head modes the lowering refuses
+    out = hip(x.to(DEV), "infer")
+    assert isinstance(out["detect"], list) and len(out["detect"]) == 3 and len(out["segment"]) == 2 and out["img_cls"].shape == (2, 2)
+    hip.detect.eval()
+    with pytest.raises(NotImplementedError):
+        hip(x.to(DEV), "train")
+
+
 def test_training_step_with_the_reference_loss_fp32():
     """forward(train) -> the trainer's `_multitask_loss` (oracle restatement, plain torch ops on the returned tensors) -> backward:
     what `running_main_v3.py:393-445` does.  Only the Detect maps, the prototypes and the image logits reach the loss, so Segment's

@@ -181,6 +181,60 @@ def test_fuse_backward(dtype, mode):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 3, 4])
+def test_resample_backward_of_the_src_model_py_neck(dtype, mode):
+    """reference src/model.py:60-74: the WeightedAdd inputs are identity, F.interpolate(scale_factor=2, mode="nearest") and F.max_pool2d(., 2);
+    mtbt_resample_backward = their transposes.  The pooled input carries exact TIES (constant windows, equal pairs): torch routes the
+    gradient to the first maximum in row-major order, so must the kernel."""
+    lib = L.load()
+    torch.manual_seed(10 + mode)
+    N, Cc, H, W = 2, 16, 6, 10
+    hi, wi = {0: (H, W), 3: (H // 2, W // 2), 4: (2 * H, 2 * W)}[mode]
+    x = torch.randn(N, Cc, hi, wi).to(dtype).float()
+    if mode == 4:
+        x[:, :, 0:2, 0:2] = 0.5                       # a constant window
+        x[:, :, 2, 2] = x[:, :, 3, 3] = 9.0           # first and last position tie
+        x[:, :, 4, 5] = x[:, :, 5, 4] = 9.0           # second and third position tie
+    x.requires_grad_()
+    dy = torch.randn(N, Cc, H, W).to(dtype).float()
+    r = x if mode == 0 else (F.interpolate(x, scale_factor=2, mode="nearest") if mode == 3 else F.max_pool2d(x, 2))
+    r.backward(dy)
+    dyd, xd = nhwc(dy, dtype), nhwc(x.detach(), dtype)
+    for accumulate in (0, 1):
+        prev = torch.randn(N, hi, wi, Cc).to(dtype)
+        dx = prev.clone().to(DEV)
+        L.check(lib.mtbt_resample_backward(dyd.data_ptr(), xd.data_ptr(), mode, dx.data_ptr(), accumulate, N, H, W, Cc, CODE[dtype], S()), "resample bwd")
+        torch.cuda.synchronize()
+        got = back(dx) - (prev.float().permute(0, 3, 1, 2) if accumulate else 0.0)
+        close(got, x.grad, TOL[dtype] * 4, f"dx accumulate={accumulate}")
+    assert lib.mtbt_resample_backward(dx.data_ptr(), None, 4, dx.data_ptr(), 0, N, H, W, Cc, CODE[dtype], S()) != 0     # max pooling needs the forward input
+    assert lib.mtbt_resample_backward(dx.data_ptr(), dx.data_ptr(), 1, dx.data_ptr(), 0, N, H, W, Cc, CODE[dtype], S()) != 0  # bilinear: mtbt_bifpn_fuse_backward
+
+
+def test_wadd_norm_weights_of_the_src_model_py_neck():
+    """reference src/model.py:27-37: w = relu(w); w = w / (w.sum() + eps); out = sum(w_i + f_i).  The output gets s / (s + eps) added to every
+    element, so d w_j = [w_j > 0] eps / (s + eps)^2 sum(dy)."""
+    lib = L.load()
+    for vals in ([0.7, 1.3], [1.2, -0.3, 0.8], [0.0, 2.0]):
+        n, Cc = len(vals), 24
+        w = torch.tensor(vals, requires_grad=True)
+        f = [torch.randn(2, Cc, 4, 5) for _ in range(n)]
+        wn = F.relu(w) / (F.relu(w).sum() + 1e-4)
+        y = sum(w_i + f_i for w_i, f_i in zip(wn, f))
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        wd = w.detach().to(DEV)
+        out = torch.empty(n, device=DEV)
+        L.check(lib.mtbt_wadd_norm_weights(wd.data_ptr(), n, 1e-4, out.data_ptr(), S()), "wadd norm")
+        colsum = dy.sum(dim=(0, 2, 3)).to(DEV).contiguous()
+        dw = torch.full((n,), 3.0, device=DEV)
+        L.check(lib.mtbt_wadd_norm_weights_backward(wd.data_ptr(), n, 1e-4, colsum.data_ptr(), Cc, dw.data_ptr(), 1, S()), "wadd norm bwd")
+        torch.cuda.synchronize()
+        close(out, wn.detach(), 1e-6, "wadd norm")
+        close(dw - 3.0, w.grad, 1e-4, "wadd norm bwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_projector_backward(dtype):
     lib = L.load()
     torch.manual_seed(1)
