@@ -134,6 +134,15 @@ def test_src_model_py_variant_trains_fp32():
     hip.detect.eval()
     with pytest.raises(NotImplementedError):
         hip(x.to(DEV), "train")
+    # bf16 arithmetic: same plan shape, outputs within bf16 rounding of the fp32 oracle, a finite gradient for every parameter
+    hip.train().set_compute_dtype(torch.bfloat16)
+    hip.zero_grad(set_to_none=True)
+    hb16 = flat_outputs(hip(x.to(DEV), "train"))
+    for r, h in zip(ro, hb16):
+        assert ((h.detach().float().cpu() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6)).item() < 8e-2
+    sum((h * w.to(DEV)).sum() for h, w in zip(hb16, probes)).backward()
+    torch.cuda.synchronize()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hip.parameters() if p.requires_grad)
 
 
 def test_training_step_with_the_reference_loss_fp32():
