@@ -227,11 +227,12 @@ def test_wadd_norm_weights_of_the_src_model_py_neck():
         out = torch.empty(n, device=DEV)
         L.check(lib.mtbt_wadd_norm_weights(wd.data_ptr(), n, 1e-4, out.data_ptr(), S()), "wadd norm")
         colsum = dy.sum(dim=(0, 2, 3)).to(DEV).contiguous()
-        dw = torch.full((n,), 3.0, device=DEV)
+        dw = torch.full((n,), 123.0, device=DEV)                                  # overwritten, then accumulated onto
+        L.check(lib.mtbt_wadd_norm_weights_backward(wd.data_ptr(), n, 1e-4, colsum.data_ptr(), Cc, dw.data_ptr(), 0, S()), "wadd norm bwd")
         L.check(lib.mtbt_wadd_norm_weights_backward(wd.data_ptr(), n, 1e-4, colsum.data_ptr(), Cc, dw.data_ptr(), 1, S()), "wadd norm bwd")
         torch.cuda.synchronize()
         close(out, wn.detach(), 1e-6, "wadd norm")
-        close(dw - 3.0, w.grad, 1e-4, "wadd norm bwd")
+        close(0.5 * dw, w.grad, 1e-4, "wadd norm bwd")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
