@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.mtbt_abi_version() == L.ABI_VERSION == 4
+    assert lib.mtbt_abi_version() == L.ABI_VERSION == 5
     assert lib.mtbt_target_arch() == b"gfx950"
 
 
