@@ -44,7 +44,8 @@ class GraphedInference:
                 del g
                 model.__dict__.get("_plans", {}).clear()
                 return dt
-            best = timed(dict(opts))
+            timed(dict(opts))                                 # thrown away: the first candidate of a process reads 2 - 4 % slow (clocks, caches, code
+            best = timed(dict(opts))                          # objects): timed once, the defaults lost to whatever came next
             if log:
                 log(f"autotune: defaults {best * 1e3:.3f} ms")
             for name, values in AUTOTUNE_KNOBS:
