@@ -69,10 +69,6 @@ def main():
             continue
         print(f"== {name}", flush=True)
         for hn, h in HINTS:
-            if "x" in hn and shape[3] % int(hn.split()[1].split("x")[0]) and int(hn.split()[1].split("x")[0]) > shape[3]:
-                continue
-            if shape[4] == 1 and h and (h >> 28) == 2 and False:
-                continue
             t = chain_time(shape, h)
             print(f"   {hn:18s}: {t if isinstance(t, str) else f'{t:6.2f} us per launch'}", flush=True)
 
