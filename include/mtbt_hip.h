@@ -121,6 +121,10 @@ int64_t mtbt_conv_colsum_workspace_bytes(int64_t pixels /* N*Ho*Wo */, int K, in
 /* colsum may be NULL with colsum_ws set: only the partial rows are written (rows x pitch floats, a row = [sums (K) | sums of squares (K)]
  * of one pixel tile's wave row) for a consumer that reduces them itself; this reports the layout a call with the same arguments produces. */
 int mtbt_conv_colsum_layout(const mtbt_conv_args* a, int64_t* rows, int32_t* pitch);
+/* Which kernel and tile mtbt_conv2d_nhwc would run for these arguments (nothing is launched, no pointer is dereferenced):
+ * choice[0] = 0 implicit GEMM / 1 direct 3x3 (LDS-resident halo) / 2 streaming head conv; [1] channel tile; [2] pixel tile (256 = the
+ * 16 x 16 halo tile); [3] = 128-byte K-steps (implicit GEMM) or first formulation (direct).  For tests of the tile rules and tools. */
+int mtbt_conv_kernel_choice(const mtbt_conv_args* a, int32_t* choice);
 
 /* ---------------------------------------------------------------------------------------------
  * ConvNeXt stem: Conv2d(3,Cout,4,stride 4,bias) on the caller's NCHW fp32 image + LayerNorm2d.

@@ -159,6 +159,7 @@ SYMBOLS = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtbt_conv_colsum_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mtbt_conv_colsum_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtbt_conv_kernel_choice": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mtbt_bn_forward_partials_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int64, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtbt_bn_backward_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),

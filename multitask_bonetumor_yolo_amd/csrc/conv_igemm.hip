@@ -120,7 +120,7 @@ static int colsum_finish(const mtbt_conv_args* a, const ConvP& p, long rows, hip
 }
 
 // `layout` non-null: validate and choose the kernel as a launch would, report the column-sum partial layout, launch nothing.
-static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [2]: rows, pitch */) {
+static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [6]: rows, pitch, kernel kind, TC, TP, 128-byte K-steps */) {
   if (!a || !a->x || !a->w || !a->y) return MTBT_EINVAL;
   if (a->dtype != MTBT_F32 && a->dtype != MTBT_BF16 && a->dtype != MTBT_F16) return MTBT_EINVAL;
   if (a->out_dtype != a->dtype && a->out_dtype != MTBT_F32) return MTBT_EINVAL;
@@ -178,7 +178,10 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // narrow 1x1 convolutions into an fp32 map (the heads' output convs): streaming kernel, same arithmetic (a tile hint keeps the call on
   // the implicit-GEMM kernel: tests, A/B)
-  if (!a->tile_hint && !layout && (pol & 64) == 0 && (long)a->K * a->C * es < 0x7fff0000L && mtbt_pw_stream_applies(p, a->dtype, (pol & 128) != 0)) return mtbt_pw_stream(p, a->dtype, s);
+  if (!a->tile_hint && (pol & 64) == 0 && (long)a->K * a->C * es < 0x7fff0000L && mtbt_pw_stream_applies(p, a->dtype, (pol & 128) != 0)) {
+    if (layout) { layout[0] = layout[1] = 0; layout[2] = 2; layout[3] = a->K; layout[4] = 128; layout[5] = 0; return MTBT_OK; }   // (no column sums on this path)
+    return mtbt_pw_stream(p, a->dtype, s);
+  }
   // 3x3 / stride 1 / pad 1 on 16-aligned maps: direct convolution with an LDS-resident halo tile (conv3x3_direct.inc).
   // tile_hint bit 26 (or MTBT_CONV_POLICY bit 2 cleared) keeps such a conv on the implicit-GEMM kernel (tests, A/B).
   {
@@ -191,7 +194,7 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
       // selects the first formulation, hint bit 25 / policy bit 3 force this one
       if ((pol & 8) || ((a->tile_hint >> 25) & 1) || !(pol & 16)) tc |= 0x1000;
       const long rows = (long)a->N * (a->H >> 4) * (a->W >> 4) * ((tc & 0x1000) ? 2 : 4);   // partial rows per 16x16 tile: see conv3x3_direct.inc
-      if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; return MTBT_OK; }
+      if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; layout[2] = 1; layout[3] = tc & 0xfff; layout[4] = 256; layout[5] = (tc & 0x1000) ? 0 : 1; return MTBT_OK; }
       if (want_cs && a->colsum_ws_bytes < rows * p.cs_pitch * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
       const int rc = a->dtype == MTBT_F32 ? mtbt_conv3x3_direct_f32(p, tc, s) : (a->dtype == MTBT_F16 ? mtbt_conv3x3_direct_f16(p, tc, s) : mtbt_conv3x3_direct_bf16(p, tc, s));
       if (rc != MTBT_OK || !a->colsum) return rc;
@@ -207,7 +210,7 @@ static int conv_impl(const mtbt_conv_args* a, void* stream, int64_t* layout /* [
   if (nbuf < 2 || nbuf > 4) nbuf = pick_nbuf(TC, TP, wide ? 128 : 64, a->R * a->S * a->C / ((wide ? 128 : 64) / es));
   const int waves_p = (TC == 128 || (TC == 96 && TP == 64)) ? 2 : 4;    // wave layouts of conv_igemm.inc's dispatch_tile
   const long rows = (((long)p.M + TP - 1) / TP) * waves_p;
-  if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; return MTBT_OK; }
+  if (layout) { layout[0] = rows; layout[1] = p.cs_pitch; layout[2] = 0; layout[3] = TC; layout[4] = TP; layout[5] = wide; return MTBT_OK; }
   if (want_cs && a->colsum_ws_bytes < rows * p.cs_pitch * (int64_t)sizeof(float)) return MTBT_EWORKSPACE;
   const int rc = a->dtype == MTBT_F32 ? mtbt_conv_dispatch_f32(p, TC, TP, wide, nbuf, s)
                                       : (a->dtype == MTBT_F16 ? mtbt_conv_dispatch_f16(p, TC, TP, wide, nbuf, s) : mtbt_conv_dispatch_bf16(p, TC, TP, wide, nbuf, s));
@@ -222,9 +225,22 @@ extern "C" int mtbt_conv2d_nhwc(const mtbt_conv_args* a, void* stream) { return 
 // (mtbt_bn_forward_partials_nhwc) instead of asking for the finished sums.
 extern "C" int mtbt_conv_colsum_layout(const mtbt_conv_args* a, int64_t* rows, int32_t* pitch) {
   if (!rows || !pitch || !a || !a->colsum_ws) return MTBT_EINVAL;
-  int64_t lay[2] = {0, 0};
+  int64_t lay[6] = {0, 0, 0, 0, 0, 0};
   const int rc = conv_impl(a, nullptr, lay);
   if (rc != MTBT_OK) return rc;
   *rows = lay[0]; *pitch = (int32_t)lay[1];
+  return MTBT_OK;
+}
+
+// Which kernel and tile a call with these arguments runs (nothing is launched, no pointer is dereferenced): choice[0] = 0 implicit GEMM,
+// 1 direct 3x3 with an LDS-resident halo, 2 streaming head conv; [1] channel tile; [2] pixel tile (256 = the 16 x 16 halo tile; the
+// streaming kernel: 128 pixels per workgroup); [3] = 128-byte K-steps (implicit GEMM) / first formulation (direct).  For tests of the tile
+// rules (tests/test_cpu_host_logic.py) and for tools.
+extern "C" int mtbt_conv_kernel_choice(const mtbt_conv_args* a, int32_t* choice) {
+  if (!a || !choice) return MTBT_EINVAL;
+  int64_t lay[6] = {0, 0, 0, 0, 0, 0};
+  const int rc = conv_impl(a, nullptr, lay);
+  if (rc != MTBT_OK) return rc;
+  for (int i = 0; i < 4; ++i) choice[i] = (int32_t)lay[2 + i];
   return MTBT_OK;
 }

@@ -249,3 +249,53 @@ def test_plan_option_precedence(monkeypatch):
     assert M.plan_option(m, "LANES") is None              # scheduler knobs default to "not set" (engine.Plan reads its own defaults)
     m.plan_options = {"SEG_GATE": None}
     assert M.plan_option(m, "SEG_GATE") == "2"             # an explicit None falls through to the environment
+
+
+def test_conv_tile_rules_follow_the_round_structure():
+    """`mtbt_conv_kernel_choice` (no launch, no GPU): the tile rules of round 3, measured per launch inside a captured chain
+    (profiles/r03_chain_tune.txt) -- 128-byte K-steps wherever the row allows; 300 .. 512 workgroups of the LARGEST tile that yields that many
+    (one round on the 512 workgroup slots) before twice as many half tiles; 513 .. 1023 avoided; 64-pixel tiles for the heads' narrow outputs;
+    the streaming kernel only for the 64 -> 32 coefficient convs; 3x3 on 16-aligned maps on the direct kernel."""
+    import ctypes as C
+    from multitask_bonetumor_yolo_amd import _lib as L
+    lib = L.load()
+
+    def choice(N, H, W, Cin, K, k=1, stride=1, act=L.ACT_SILU, dtype=L.BF16, out_dtype=None, shift=True):
+        a = L.ConvArgs()
+        a.x, a.w, a.y = 0x10000, 0x20000, 0x30000              # never dereferenced by the query
+        a.shift = 0x40000 if shift else None
+        pad = k // 2 if stride == 1 else 0
+        a.N, a.H, a.W, a.C, a.K, a.R, a.S, a.stride, a.pad = N, H, W, Cin, K, k, k, stride, pad
+        a.Ho, a.Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        a.x_pixel_stride, a.x_batch_stride = Cin, H * W * Cin
+        a.y_pixel_stride, a.y_batch_stride = K, a.Ho * a.Wo * K
+        a.dtype, a.out_dtype, a.act, a.out_mode = dtype, dtype if out_dtype is None else out_dtype, act, L.OUT_NHWC
+        out = (C.c_int32 * 4)()
+        assert lib.mtbt_conv_kernel_choice(C.byref(a), out) == 0
+        return tuple(out)
+
+    # 1x1 at 40 x 40 (25 600 pixels): K = 256 -> 400 tiles of 128 x 128 = one round; K = 384 would be 600 (a second, mostly empty round) -> 128 x 64
+    assert choice(16, 40, 40, 256, 256) == (0, 128, 128, 1)
+    assert choice(16, 40, 40, 512, 256) == (0, 128, 128, 1)
+    assert choice(16, 40, 40, 384, 384) == (0, 128, 64, 1)
+    assert choice(16, 40, 40, 768, 384) == (0, 128, 64, 1)
+    # 20 x 20 (6 400 pixels): 64 x 64 tiles (400 workgroups) for K = 256, 128 x 64 (400) for K = 512, 128 x 128 once that gives 300
+    assert choice(16, 20, 20, 256, 256) == (0, 64, 64, 1)
+    assert choice(16, 20, 20, 768, 512) == (0, 128, 64, 1)
+    assert choice(16, 20, 20, 3072, 768, act=L.ACT_NONE) == (0, 128, 128, 1)
+    # large grids: 128 x 128, and 128-byte K-steps also for the short rows the round-2 rule gave 64-byte steps
+    assert choice(16, 80, 80, 256, 256) == (0, 128, 128, 1)
+    assert choice(16, 80, 80, 192, 256) == (0, 128, 128, 1)
+    assert choice(16, 160, 160, 96, 192, k=2, stride=2, act=L.ACT_NONE)[3] == 0        # 192-byte rows: not a multiple of 128
+    # the heads: narrow outputs on 64-pixel implicit-GEMM tiles, the streaming kernel for the 64 -> 32 coefficient convs only
+    assert choice(16, 80, 80, 64, 64, act=L.ACT_NONE, out_dtype=L.F32) == (0, 64, 64, 1)
+    assert choice(16, 40, 40, 256, 2, act=L.ACT_NONE, out_dtype=L.F32) == (0, 32, 64, 1)
+    assert choice(16, 20, 20, 64, 32, act=L.ACT_NONE, out_dtype=L.F32)[0] == 2
+    # 3x3: the direct kernel with the LDS-resident halo on 16-aligned maps (row-reuse form), the implicit GEMM elsewhere
+    assert choice(16, 80, 80, 128, 128, k=3)[:2] == (1, 128) and choice(16, 80, 80, 128, 128, k=3)[3] == 0
+    assert choice(16, 80, 80, 256, 64, k=3)[:2] == (1, 64)
+    assert choice(16, 40, 40, 128, 128, k=3) == (0, 128, 64, 1)
+    assert choice(16, 20, 20, 256, 256, k=3) == (0, 64, 64, 1)
+    assert choice(16, 80, 80, 192, 384, k=2, stride=2, act=L.ACT_NONE) == (0, 128, 64, 1)   # 600 tiles of 128 x 128 -> half tiles
+    # fp32 (the parity mode) follows the same rules with 32-element rows
+    assert choice(2, 40, 40, 256, 256, dtype=L.F32)[0] == 0
