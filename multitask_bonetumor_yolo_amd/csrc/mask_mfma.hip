@@ -43,7 +43,10 @@ constexpr int PPITCH = NM + 1;  // patch row pitch (floats): conflict-free colum
 // LW x LH low-res pixels per tile = a 4 LW x 4 LH output tile.  16 x 16 (64 x 64 outputs) is the general shape; 32 x 8 (128 x 32 outputs)
 // when the width allows: a mask row of the tile is then a whole 128-byte line -- with 64-byte rows two workgroups each wrote HALF of every
 // line of the uint8 masks (2.2 TB/s of output at 640x640; the kernel is nothing but that write).
-template <int LW, int LH>
+// MASKS_ONLY: the post-process form (no logits output) as its own instantiation.  As a run-time branch next to the general path the compiler
+// merged the two paths' mask stores into a shared tail and split this path's 16-byte store into a dword + a dwordx3 (ISA of round 3): every
+// 64-byte line of the largest write of the step was then written by two instructions in pieces of 4 and 12 bytes.
+template <int LW, int LH, bool MASKS_ONLY>
 __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
   constexpr int PW = LW + 2, PH = LH + 2;          // patch = tile + halo
   constexpr int NPX = PW * PH;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void mask_x4_kernel(const MaskX4P p) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) { t0[c] = r0[c]; t1[c] = r1[c]; }
         const long obase_m = (((long)n * p.K + g0 + b) * p.Hout + oy) * p.Wout + ox0;
-        if (!p.logits) {
+        if constexpr (MASKS_ONLY) {
           // Masks only (the post-process path: 16 x 100 x 640^2 bytes per step, the largest single write of the step).  The kernel is
           // VALU-bound, not HBM-bound (~140 vector instructions per 16 stored bytes in the logits form): so the vertical taps go FIRST --
           // 6 columns x 2 + 16 pixels x 2 multiply-adds instead of 16 x 6 -- and the threshold + byte packing is one FMA and one
@@ -212,8 +215,13 @@ static int launch_mask_x4(MaskX4P& p, const mtbt_mask_args* a, hipStream_t strea
   p.tiles_x = a->Wout / (4 * LW);
   p.tiles_y = (a->Hout + 4 * LH - 1) / (4 * LH);
   const size_t lds = (size_t)(NPXP * PPITCH + 16 * PPITCH + 16 * (NPXP + 4)) * sizeof(float);
-  if (int rc = mtbt_allow_lds(mask_x4_kernel<LW, LH>, (int)lds)) return rc;
-  hipLaunchKernelGGL((mask_x4_kernel<LW, LH>), dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
+  if (!a->logits && a->masks) {
+    if (int rc = mtbt_allow_lds(mask_x4_kernel<LW, LH, true>, (int)lds)) return rc;
+    hipLaunchKernelGGL((mask_x4_kernel<LW, LH, true>), dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
+  } else {
+    if (int rc = mtbt_allow_lds(mask_x4_kernel<LW, LH, false>, (int)lds)) return rc;
+    hipLaunchKernelGGL((mask_x4_kernel<LW, LH, false>), dim3(p.tiles_x * p.tiles_y, a->N), dim3(256), lds, stream, p);
+  }
   MTBT_LAUNCH_CHECK();
   return MTBT_OK;
 }

@@ -9,6 +9,6 @@ extern "C" int mask_variant(int dbg, const float* protos, const float* coeff, lo
   p.protos = protos; p.coeff = coeff; p.cbs = cbs; p.cks = cks; p.ccs = ccs; p.gather = gather; p.counts = counts; p.bias = 0.f;
   p.N = N; p.K = K; p.hp = hp; p.wp = wp; p.Hout = 4 * hp; p.Wout = 4 * wp; p.logits = nullptr; p.masks = masks; p.dbg = dbg;
   mtbt_mask_args a{};
-  a.N = N; a.Hout = 4 * hp; a.Wout = 4 * wp;
+  a.N = N; a.Hout = 4 * hp; a.Wout = 4 * wp; a.masks = masks;
   return launch_mask_x4<32, 8>(p, &a, reinterpret_cast<hipStream_t>(stream));
 }
