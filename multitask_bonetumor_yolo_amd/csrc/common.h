@@ -74,8 +74,11 @@ template <> __device__ __forceinline__ void ld8<f16_t>(const f16_t* p, float (&v
 }
 template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  // two <4 x float> stores as VECTORS (ext_vector_type): written as HIP float4 structs they reach the optimiser as eight scalar stores, and
+  // next to a scalar tail path that writes the same addresses it regrouped them as 12 + 16 + 4 bytes -- a dwordx3, a MISALIGNED dwordx4 and a
+  // dword per 32 bytes (ISA of round 3: the fp32 maps of the heads and of Proto cv3)
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
   uint4 u;

@@ -54,7 +54,7 @@ static void pick_tile(int pol, int K, long M, int taps, int C, int es, int* TC, 
     //   * what decides the tile is the ROUND structure on the 512 workgroup slots (256 CUs x 2): 300 - 512 workgroups of the largest tile
     //     that gives that many -- one full round -- beat twice as many half tiles (256 -> 256 @40x40: 128x128 11.3 us, 128x64 14.3;
     //     512 -> 256 @40x40: 15.8 against 21.5) and 513 - 1023 is the worst place to be (a second, mostly empty round: 384 -> 384 @40x40);
-    //   * 64-channel and narrower outputs (the heads): 64-pixel tiles at every level.
+    //   * 64-channel outputs (the heads' box convs): 64-pixel tiles at every level; narrower ones run on the streaming kernel (pw_stream.hip).
     const bool can_wide = (C * es) % 128 == 0;
     *narrow = can_wide ? 0 : 1;
     if (tc == 128) {

@@ -76,13 +76,14 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const ConvP p) {
     for (int j = 0; j < FP; ++j) {
       if (!ok[j]) continue;
       float* yp = yb + yoff[j] + ch;
-      const float4 v = float4{acc[i][j][0] + sh[0], acc[i][j][1] + sh[1], acc[i][j][2] + sh[2], acc[i][j][3] + sh[3]};
-      if (p.vec_ok && ch + 4 <= p.K) *reinterpret_cast<float4*>(yp) = v;
+      // a <4 x float> VECTOR store (ext_vector_type): as a HIP float4 struct it reaches the optimiser as four scalar stores, which it merged with
+      // the scalar tail below into a dword + a dwordx3 per 16 bytes (ISA of round 3; common.h st8<float> had the same disease)
+      const f32x4 v = f32x4{acc[i][j][0] + sh[0], acc[i][j][1] + sh[1], acc[i][j][2] + sh[2], acc[i][j][3] + sh[3]};
+      if (p.vec_ok && ch + 4 <= p.K) *reinterpret_cast<f32x4*>(yp) = v;
       else {
-        const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (ch + e < p.K) yp[e] = vv[e];
+          if (ch + e < p.K) yp[e] = v[e];
       }
     }
   }
@@ -119,12 +120,13 @@ int launch_t(const ConvP& p, hipStream_t s) {
 
 // Whether mtbt_conv2d_nhwc hands this call to the streaming kernel (conv_igemm.hip asks before it picks a tile).  `vec_ok` of p = 16-byte
 // fp32 stores are whole and aligned (pixel / batch stride multiples of 4 elements, aligned base): set by the caller.
-// Round 3, measured per launch inside a captured chain (tools/chain_tune.py, profiles/r03_chain_tune.txt): the 64 -> 64 box convs and the
-// 256 -> nc class convs are 15 - 25 % faster on the implicit-GEMM kernel's 64-pixel tiles (19.0 -> 15.8 us at 80x80, 6.8 -> 5.0 at 20x20) -- the
-// rocprofv3 durations that chose the streaming kernel for them do not see the launch's tail -- so it keeps the narrow shapes only (the
-// 64 -> 32 mask-coefficient convs).  Both paths give the same bits; `any_width` (policy bit 7: tests, A/B) hands it every shape it can run.
+// Round 3, measured per launch inside a captured chain (tools/chain_tune.py on the bias-only argument blocks the heads really pass, with this
+// kernel's 16-byte store whole again -- see the store below): the streaming kernel wins wherever the output is at most 32 channels wide (the
+// 256 -> nc class convs 13.6 against 15.3 us at 80x80, 5.3 / 5.9 at 40x40; the 64 -> 32 coefficient convs), the 64 -> 64 box convs are level or
+// better on the implicit-GEMM kernel's 64 x 64 tiles (12.9 against 13.7 us at 80x80, 4.7 / 5.1 at 20x20).  Both paths give the same bits;
+// `any_width` (policy bit 7: tests, A/B) hands it every shape it can run.
 bool mtbt_pw_stream_applies(const ConvP& p, int dtype, bool any_width) {
-  const bool shape = any_width ? ((p.C == 32 || p.C == 64 || p.C == 128 || p.C == 256) && p.K <= 64) : ((p.C == 32 || p.C == 64) && p.K <= 32);
+  const bool shape = (p.C == 32 || p.C == 64 || p.C == 128 || p.C == 256) && p.K <= (any_width ? 64 : 32);
   return (dtype == MTBT_BF16 || dtype == MTBT_F16) && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && shape &&
          p.out_f32 && p.out_mode == MTBT_OUT_NHWC && p.act == MTBT_ACT_NONE && !p.scale && !p.res && !p.y2 && !p.cs_part && !p.debug;
 }

@@ -287,10 +287,12 @@ def test_conv_tile_rules_follow_the_round_structure():
     assert choice(16, 80, 80, 256, 256) == (0, 128, 128, 1)
     assert choice(16, 80, 80, 192, 256) == (0, 128, 128, 1)
     assert choice(16, 160, 160, 96, 192, k=2, stride=2, act=L.ACT_NONE)[3] == 0        # 192-byte rows: not a multiple of 128
-    # the heads: narrow outputs on 64-pixel implicit-GEMM tiles, the streaming kernel for the 64 -> 32 coefficient convs only
+    # the heads: the 64 -> 64 box convs on 64-pixel implicit-GEMM tiles, outputs of at most 32 channels (class / coefficient convs, bias only) on
+    # the streaming kernel; with a scale vector (not a head conv) the narrow shape stays on the implicit GEMM
     assert choice(16, 80, 80, 64, 64, act=L.ACT_NONE, out_dtype=L.F32) == (0, 64, 64, 1)
-    assert choice(16, 40, 40, 256, 2, act=L.ACT_NONE, out_dtype=L.F32) == (0, 32, 64, 1)
+    assert choice(16, 40, 40, 256, 2, act=L.ACT_NONE, out_dtype=L.F32)[0] == 2
     assert choice(16, 20, 20, 64, 32, act=L.ACT_NONE, out_dtype=L.F32)[0] == 2
+    assert choice(16, 160, 160, 256, 32, act=L.ACT_SILU, out_dtype=L.F32) == (0, 32, 64, 1)      # Proto cv3: activation -> not the streaming kernel
     # 3x3: the direct kernel with the LDS-resident halo on 16-aligned maps (row-reuse form), the implicit GEMM elsewhere
     assert choice(16, 80, 80, 128, 128, k=3)[:2] == (1, 128) and choice(16, 80, 80, 128, 128, k=3)[3] == 0
     assert choice(16, 80, 80, 256, 64, k=3)[:2] == (1, 64)

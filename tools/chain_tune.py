@@ -39,7 +39,7 @@ def plan_shapes(img, batch):
             a = l.keep[0] if l.keep else None
             if not isinstance(a, L.ConvArgs):
                 continue
-            key = (a.N, a.H, a.W, a.C, a.K, a.R, a.stride, a.pad, a.act, bool(a.res), a.dtype, a.out_dtype, a.out_mode)
+            key = (a.N, a.H, a.W, a.C, a.K, a.R, a.stride, a.pad, a.act, bool(a.res), a.dtype, a.out_dtype, a.out_mode, bool(a.scale))
             shapes.setdefault(key, []).append(l.name)
     del model
     torch.cuda.empty_cache()
@@ -47,7 +47,7 @@ def plan_shapes(img, batch):
 
 
 def chain_time(key, hint):
-    N, H, W, C, K, R, stride, pad, act, has_res, dt, odt, om = key
+    N, H, W, C, K, R, stride, pad, act, has_res, dt, odt, om, has_scale = key
     Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
     p = Plan(DEV)
     Kq = K // 4 if om == L.OUT_CONVT2X2 else K
@@ -56,7 +56,7 @@ def chain_time(key, hint):
     ys = [Act.of(torch.empty(N, Hy, Wy, Kq, device=DEV, dtype=DT[odt])) for _ in range(RING)]
     rs = [Act.of(torch.randn(N, Hy, Wy, Kq, device=DEV).to(DT[dt])) for _ in range(RING)] if has_res else None
     w = (torch.randn(K, R * R * C, device=DEV) / (R * R * C) ** 0.5).to(DT[dt])
-    sc, sh = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+    sc, sh = (torch.ones(K, device=DEV) if has_scale else None), torch.zeros(K, device=DEV)    # (a head's output conv has a bias only: the streaming kernel's case)
     try:
         for i in range(CHAIN):
             p.conv(xs[i % RING], w, ys[i % RING], R=R, S=R, stride=stride, pad=pad, scale=sc, shift=sh, act=act, res=rs[i % RING] if rs else None,
@@ -89,7 +89,7 @@ def main():
     total_default = total_best = 0.0
     print(f"# {len(shapes)} distinct conv shapes, batch {batch} x {img}^2; per launch in a {CHAIN}-launch graph chain", flush=True)
     for key, names in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
-        N, H, W, C, K, R, stride, pad, act, has_res, dt, odt, om = key
+        N, H, W, C, K, R, stride, pad, act, has_res, dt, odt, om, has_scale = key
         label = f"{R}x{R}/{stride} {C}->{K} @{H}x{W} act{act}{' +res' if has_res else ''}{' f32out' if odt == L.F32 else ''}{' convT' if om else ''}"
         if flt and not any(f in label or any(f in n for n in names) for f in flt):
             continue
