@@ -9,6 +9,7 @@ typedef uint16_t bf16_t;  // storage type of a bf16 element
 struct f16_t { uint16_t v; };  // storage type of an IEEE binary16 element (a distinct type: the kernels dispatch on it)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // a 16-byte access the optimiser keeps whole (HIP's uint4 / float4 are structs: see st8<float>)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;

@@ -79,6 +79,15 @@ struct MlpP {
 template <typename HT> __device__ __forceinline__ uint32_t pk2(float a, float b);
 template <> __device__ __forceinline__ uint32_t pk2<bf16_t>(float a, float b) { return pk_bf16(a, b); }
 template <> __device__ __forceinline__ uint32_t pk2<f16_t>(float a, float b) { return pk_h2(a, b); }
+// Output-channel order of GEMM2.  An accumulator fragment gives a lane 4 consecutive rows (4 lq .. 4 lq + 3): stored as they are, 8 bytes of a pixel
+// row per lane -- 24 dwordx2 stores (and as many residual loads) per lane at d = 384.  The STAGED row order of W2' is therefore permuted (a free
+// change of the DMA source offsets): LDS row 16 F + 4 q + e holds output channel 32 (F / 2) + 8 q + 4 (F % 2) + e, so that a lane's rows of the
+// fragment pair (2 m, 2 m + 1) are the 8 CONSECUTIVE channels 32 m + 8 q .. + 7: one 16-byte store / residual load per pair, 64 contiguous bytes
+// of a pixel row per four lanes.  The caller's w2p / b2 / y stay in natural channel order.
+__device__ __forceinline__ int w2_row_channel(int r) {
+  const int F = r >> 4, q = (r >> 2) & 3, e = r & 3;
+  return 32 * (F >> 1) + 8 * q + 4 * (F & 1) + e;
+}
 template <typename HT> __device__ __forceinline__ f32x4 unpack4(uint2 r);
 template <> __device__ __forceinline__ f32x4 unpack4<bf16_t>(uint2 r) {
   return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
     } else {
       const int c2 = c - W1B / 16;
       const int r = c2 / 4, q = (c2 % 4) ^ swz4(r);
-      voff[i] = (unsigned)(r * 4 * D * 2 + q * 16);                  // + chunk * 64 (scalar)
+      voff[i] = (unsigned)(w2_row_channel(r) * 4 * D * 2 + q * 16);  // + chunk * 64 (scalar); row order: w2_row_channel
     }
   }
   auto stage = [&](int j, int buf) {
@@ -159,14 +168,16 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
   // row, requested here (their latency hides under the whole chunk loop) -- the epilogue then has no global load in its
   // LDS-slab chain (with one it was 80 of the kernel's 166 us at d = 96: four dependent load round trips per workgroup).
   f32x4 acc2[FC][FP];
+  static_assert(FC % 2 == 0, "fragment pairs");
 #pragma unroll
   for (int f = 0; f < FP; ++f) {
     const int pix = pbase + f * 16 + lr;
 #pragma unroll
-    for (int i = 0; i < FC; ++i) {
-      uint2 r = uint2{0u, 0u};
-      if (p.res && pix < p.M) r = *reinterpret_cast<const uint2*>(p.res + (long)pix * D + i * 16 + lq * 4);
-      acc2[i][f] = unpack4<HT>(r);
+    for (int m = 0; m < FC / 2; ++m) {        // (w2_row_channel: the pair's rows of this lane = channels 32 m + 8 lq .. + 7)
+      uint4 r = uint4{0u, 0u, 0u, 0u};
+      if (p.res && pix < p.M) r = *reinterpret_cast<const uint4*>(p.res + (long)pix * D + m * 32 + lq * 8);
+      acc2[2 * m][f] = unpack4<HT>(uint2{r.x, r.y});
+      acc2[2 * m + 1][f] = unpack4<HT>(uint2{r.z, r.w});
     }
   }
 
@@ -319,24 +330,26 @@ __global__ __launch_bounds__(256, WPS) void mlp_fused_kernel(const MlpP p) {
       }
     }
   }
-  // Epilogue: + b2' and 8-byte bf16x4 stores STRAIGHT from the accumulators (a lane owns 4 consecutive channels of a
-  // pixel; the four lq groups of a pixel write 32 contiguous bytes, the wave's FC passes complete the 2d-byte row).
+  // Epilogue: + b2' and 16-byte stores STRAIGHT from the accumulators (w2_row_channel: a lane owns 8 consecutive channels of a pixel per
+  // fragment pair; the four lq groups of a pixel write 64 contiguous bytes, the wave's FC / 2 passes complete the 2d-byte row).
   // Measured against the conv kernels' LDS-slab epilogue (16-byte stores after a transposition through LDS): 23 us
   // instead of 57 us of the kernel's time at d = 96 -- the slab's serialized LDS round trips cost more than the wider
   // stores save.
   if (p.dbg & 32) { if (acc2[0][0][0] == 123.f) reinterpret_cast<bf16_t*>(p.ep.y)[0] = 0; return; }
   bf16_t* yb = reinterpret_cast<bf16_t*>(p.ep.y);
 #pragma unroll
-  for (int i = 0; i < FC; ++i) {
-    const float4 sh = *reinterpret_cast<const float4*>(aff + D + i * 16 + lq * 4);
+  for (int m = 0; m < FC / 2; ++m) {
+    const float4 s0 = *reinterpret_cast<const float4*>(aff + D + m * 32 + lq * 8), s1 = *reinterpret_cast<const float4*>(aff + D + m * 32 + lq * 8 + 4);
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
       const int pix = pbase + f * 16 + lr;
       if (pix >= p.M) continue;
-      uint2 o;
-      o.x = pk2<HT>(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
-      o.y = pk2<HT>(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
-      *reinterpret_cast<uint2*>(yb + (long)pix * D + i * 16 + lq * 4) = o;
+      u32x4 o;
+      o.x = pk2<HT>(acc2[2 * m][f][0] + s0.x, acc2[2 * m][f][1] + s0.y);
+      o.y = pk2<HT>(acc2[2 * m][f][2] + s0.z, acc2[2 * m][f][3] + s0.w);
+      o.z = pk2<HT>(acc2[2 * m + 1][f][0] + s1.x, acc2[2 * m + 1][f][1] + s1.y);
+      o.w = pk2<HT>(acc2[2 * m + 1][f][2] + s1.z, acc2[2 * m + 1][f][3] + s1.w);
+      *reinterpret_cast<u32x4*>(yb + (long)pix * D + m * 32 + lq * 8) = o;
     }
   }
 }
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
     } else {
       const int c2 = c - W1B / 16;
       const int r = c2 / 4, sl = (c2 % 4) ^ swz4(r);
-      voff[i] = (unsigned)(r * 4 * D * 2 + sl * 16);
+      voff[i] = (unsigned)(w2_row_channel(r) * 4 * D * 2 + sl * 16);
     }
   }
   auto stage = [&](int j, int buf) {     // stage j = W1 of chunk j (j < NCH) and W2' of chunk j - 1 (j >= 1)
@@ -424,10 +437,11 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
     for (int ks = 0; ks < KS1; ++ks)
       tf[f][ks] = (pix < p.M && !MLP_ABL(p, 64)) ? *reinterpret_cast<const uint4*>(p.t + (long)pix * D + ks * 32 + lq * 8) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < FCH; ++i) {
-      uint2 r = uint2{0u, 0u};
-      if (p.res && pix < p.M) r = *reinterpret_cast<const uint2*>(p.res + (long)pix * D + (hh * FCH + i) * 16 + lq * 4);
-      acc2[i][f] = unpack4<HT>(r);
+    for (int m = 0; m < FCH / 2; ++m) {       // (w2_row_channel: this lane's rows of the fragment pair = 8 consecutive channels)
+      uint4 r = uint4{0u, 0u, 0u, 0u};
+      if (p.res && pix < p.M) r = *reinterpret_cast<const uint4*>(p.res + (long)pix * D + (hh * FCH / 2 + m) * 32 + lq * 8);
+      acc2[2 * m][f] = unpack4<HT>(uint2{r.x, r.y});
+      acc2[2 * m + 1][f] = unpack4<HT>(uint2{r.z, r.w});
     }
   }
   int a1off[KS1];
@@ -512,17 +526,21 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpP p) {
     }
   }
   HT* const yb = reinterpret_cast<HT*>(p.ep.y);
+  static_assert(FCH % 2 == 0, "fragment pairs");
 #pragma unroll
-  for (int i = 0; i < FCH; ++i) {
-    const float4 sh = *reinterpret_cast<const float4*>(aff + (hh * FCH + i) * 16 + lq * 4);
+  for (int m = 0; m < FCH / 2; ++m) {
+    const int cb = (hh * FCH / 2 + m) * 32 + lq * 8;
+    const float4 s0 = *reinterpret_cast<const float4*>(aff + cb), s1 = *reinterpret_cast<const float4*>(aff + cb + 4);
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
       const int pix = pbase + f * 16 + lr;
       if (pix >= p.M || MLP_ABL(p, 32)) continue;
-      uint2 o;
-      o.x = pk2<HT>(acc2[i][f][0] + sh.x, acc2[i][f][1] + sh.y);
-      o.y = pk2<HT>(acc2[i][f][2] + sh.z, acc2[i][f][3] + sh.w);
-      *reinterpret_cast<uint2*>(yb + (long)pix * D + (hh * FCH + i) * 16 + lq * 4) = o;
+      u32x4 o;
+      o.x = pk2<HT>(acc2[2 * m][f][0] + s0.x, acc2[2 * m][f][1] + s0.y);
+      o.y = pk2<HT>(acc2[2 * m][f][2] + s0.z, acc2[2 * m][f][3] + s0.w);
+      o.z = pk2<HT>(acc2[2 * m + 1][f][0] + s1.x, acc2[2 * m + 1][f][1] + s1.y);
+      o.w = pk2<HT>(acc2[2 * m + 1][f][2] + s1.z, acc2[2 * m + 1][f][3] + s1.w);
+      *reinterpret_cast<u32x4*>(yb + (long)pix * D + cb) = o;
     }
   }
 }
