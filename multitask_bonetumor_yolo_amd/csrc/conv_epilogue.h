@@ -38,6 +38,16 @@ template <> __device__ __forceinline__ float stored_value<float>(float v) { retu
 template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return __uint_as_float((unsigned)f2bf(v) << 16); }
 template <> __device__ __forceinline__ float stored_value<f16_t>(float v) { return h2f(f2h(v)); }
 
+// PERM: the kernel staged its weight tile in the PERMUTED row order below (a free change of the DMA source offsets): inside a wave's channel
+// block, LDS row 16 F + 4 q + e holds channel 32 (F / 2) + 8 q + 4 (F % 2) + e.  A lane's accumulator rows (4 q .. 4 q + 3 of every fragment)
+// of the fragment PAIR (2 m, 2 m + 1) are then the 8 CONSECUTIVE channels 32 m + 8 q .. + 7 -- one 16-byte piece of the NHWC output row, stored
+// straight from the accumulators (conv_epilogue_direct) instead of through the LDS slab transposition.  The slab bodies write at epi_cpos.
+__device__ __forceinline__ int epi_row_channel(int r) {
+  const int F = r >> 4, q = (r >> 2) & 3, e = r & 3;
+  return 32 * (F >> 1) + 8 * q + 4 * (F & 1) + e;
+}
+template <bool PERM> __device__ __forceinline__ int epi_cpos(int i, int lq) { return PERM ? 32 * (i >> 1) + 8 * lq + 4 * (i & 1) : i * 16 + lq * 4; }
+
 template <int C8>
 __device__ __forceinline__ void colsum_flush(const ConvP& p, float (&cs)[8], float (&cq)[8], long srow, int ch, bool ch_ok, int lane) {
   static_assert((C8 & (C8 - 1)) == 0 && C8 <= 64, "lanes sharing a channel piece differ in whole lane bits");
@@ -65,7 +75,7 @@ __device__ __forceinline__ void colsum_flush(const ConvP& p, float (&cs)[8], flo
 // ragged-tail code next to every vector store) the epilogue of the 128x64 tile was ~12 000 instructions with 1 160 scalar branches for a
 // main loop of 16 MFMAs: tens of KiB of code streamed through the instruction cache per tile and a taken branch every few instructions.
 // ACT = -1 is the run-time form (ragged outputs: the nc-channel class conv, the 66-wide detect map).
-template <typename T, int TC, int FC, int FP, bool TRAIN, int ACT, bool VEC, typename AddrFn>
+template <typename T, int TC, int FC, int FP, bool TRAIN, int ACT, bool VEC, bool PERM = false, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
                                                    int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, long srow) {
   constexpr int WCH = FC * 16;
@@ -90,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
   for (int j = 0; j < FP; ++j) {
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
-      const int cl = chl0 + i * 16 + lq * 4;
+      const int cl = chl0 + epi_cpos<PERM>(i, lq);
       const float4 sh = *reinterpret_cast<const float4*>(aff + TC + cl);
       float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       if (has_scale) {
@@ -101,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue_body(const ConvP& p, f32x4 (&acc)[
       if (!late_act) {   // the usual case: activation here, on the accumulators (wave-uniform branch)
         v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
       }
-      *reinterpret_cast<float4*>(slab + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
+      *reinterpret_cast<float4*>(slab + lr * PITCH + epi_cpos<PERM>(i, lq) * 4) = v;
     }
     // wave-local hand-off through LDS (other lanes' data): a compiler barrier is REQUIRED -- the float4 row reads
     // below are a different type from the stores above and would otherwise be hoisted over them
@@ -183,7 +193,7 @@ struct EpiSeq { long pix0; int jstep; long npix; long ybias, rbias; };
 // direct 3x3 kernels, which have no room for the whole tile's.
 // DB: the wave owns TWO slab regions (slab, slab + 16 * PITCH): slab j + 1 is written while slab j is read back, one LDS round trip per slab
 // instead of two (implicit-GEMM kernels: their LDS has the room).
-template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, int RESPF = 0, bool DB = false>
+template <typename T, int TC, int FC, int FP, int ACT, int MODE, bool SUMS = false, int RESPF = 0, bool DB = false, bool PERM = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase, int chl0, int lane,
                                                    const EpiSeq q, long srow = -1) {
   constexpr int WCH = FC * 16;
@@ -197,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
   if (HOIST) {
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
-      const int cl = chl0 + i * 16 + lq * 4;
+      const int cl = chl0 + epi_cpos<PERM>(i, lq);
       sc[HOIST ? i : 0] = *reinterpret_cast<const float4*>(aff + cl);
       sh[HOIST ? i : 0] = *reinterpret_cast<const float4*>(aff + TC + cl);
     }
@@ -255,7 +265,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
       float4 s4, h4;
       if (HOIST) { s4 = sc[HOIST ? i : 0]; h4 = sh[HOIST ? i : 0]; }
       else {
-        const int cl = chl0 + i * 16 + lq * 4;
+        const int cl = chl0 + epi_cpos<PERM>(i, lq);
         s4 = *reinterpret_cast<const float4*>(aff + cl);
         h4 = *reinterpret_cast<const float4*>(aff + TC + cl);
       }
@@ -263,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
       v.x = fmaf(acc[i][j][0], s4.x, h4.x); v.y = fmaf(acc[i][j][1], s4.y, h4.y);
       v.z = fmaf(acc[i][j][2], s4.z, h4.z); v.w = fmaf(acc[i][j][3], s4.w, h4.w);
       if (MODE == 0) { v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT); }
-      *reinterpret_cast<float4*>(sb + lr * PITCH + (i * 16 + lq * 4) * 4) = v;
+      *reinterpret_cast<float4*>(sb + lr * PITCH + epi_cpos<PERM>(i, lq) * 4) = v;
     }
   };
   char* const slab0 = slab;
@@ -325,21 +335,79 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& p, f32x4 (&acc)[
   if constexpr (SUMS && (C8 & (C8 - 1)) == 0) colsum_flush<C8>(p, cs, cq, srow, cs_ch, cs_ch < p.K, lane);
 }
 
+// The DIRECT body (PERM kernels, 16-bit NHWC output, MODE 0: y = act(affine) (+ res)): no LDS at all.  Per fragment pair m the lane's 4 + 4
+// accumulators of a pixel are 8 consecutive channels (see epi_row_channel): scale / shift / activation in registers, one 16-byte residual
+// load, one 16-byte store.  A wave's store instruction covers 16 pixels x 64 contiguous bytes; the pair index completes the rows.  The residual
+// pieces of a pair are requested before its first store (the residual may BE the output: a lane reads exactly the pieces it writes).
+template <typename T, int TC, int FC, int FP, int ACT>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvP& p, f32x4 (&acc)[FC][FP], const float* aff, int cbase, int chl0, int lane, const EpiSeq q) {
+  static_assert(FC % 2 == 0 && sizeof(T) == 2, "fragment pairs, 16-bit storage");
+  typedef typename half_of<T>::type HT;
+  const int lr = lane & 15, lq = lane >> 4;
+  HT* const yp = reinterpret_cast<HT*>(p.y);
+  const T* const rp = reinterpret_cast<const T*>(p.res);
+  const bool has_res = p.res != nullptr;
+  const long px0 = q.pix0 + lr;
+#pragma unroll
+  for (int m = 0; m < FC / 2; ++m) {
+    const int cl = chl0 + m * 32 + lq * 8;
+    const int ch = cbase + cl;
+    if (ch >= p.K) continue;                 // (K is a multiple of 8 on this path)
+    const float4 s0 = *reinterpret_cast<const float4*>(aff + cl), s1 = *reinterpret_cast<const float4*>(aff + cl + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(aff + TC + cl), h1 = *reinterpret_cast<const float4*>(aff + TC + cl + 4);
+    u32x4 rv[FP];
+    if (has_res) {
+#pragma unroll
+      for (int j = 0; j < FP; ++j) {
+        const long px = px0 + (long)j * q.jstep;
+        rv[j] = u32x4{0u, 0u, 0u, 0u};
+        if (px < q.npix) rv[j] = *reinterpret_cast<const u32x4*>(rp + q.rbias + px * p.ldr + ch);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+      const long px = px0 + (long)j * q.jstep;
+      if (px >= q.npix) continue;
+      float v[8];
+      v[0] = act_apply(fmaf(acc[2 * m][j][0], s0.x, h0.x), ACT); v[1] = act_apply(fmaf(acc[2 * m][j][1], s0.y, h0.y), ACT);
+      v[2] = act_apply(fmaf(acc[2 * m][j][2], s0.z, h0.z), ACT); v[3] = act_apply(fmaf(acc[2 * m][j][3], s0.w, h0.w), ACT);
+      v[4] = act_apply(fmaf(acc[2 * m + 1][j][0], s1.x, h1.x), ACT); v[5] = act_apply(fmaf(acc[2 * m + 1][j][1], s1.y, h1.y), ACT);
+      v[6] = act_apply(fmaf(acc[2 * m + 1][j][2], s1.z, h1.z), ACT); v[7] = act_apply(fmaf(acc[2 * m + 1][j][3], s1.w, h1.w), ACT);
+      if (has_res) {
+        float r[8];
+        ld8<T>(reinterpret_cast<const T*>(&rv[j]), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      st8<HT>(yp + q.ybias + px * p.ldy + ch, v);
+    }
+  }
+}
+
+// Direct or slab?  Same-box library A/Bs (round 3): the direct body is 3 - 6 % faster per launch on the P3 / P4 shapes of the batch-16 forward (a
+// few rounds of tiles: the slab's LDS round trips are exposed latency; step -1.0 ... -1.6 %), level on the 1280 x 1280 batch-64 forward and ~0.5 %
+// slower on the batch-32 training step (many rounds, bandwidth-bound: the slab's whole-row stores beat 64-byte pieces).  A run-time switch on the
+// pixel count compiled BOTH bodies into every kernel and lost the inference gain again (code size): the direct body is unconditional.
+
 // Dispatcher: ONE switch per call.  `seq` non-null = the caller's output pixels form the arithmetic sequence the fast body wants.
-template <typename T, int TC, int FC, int FP, bool TRAIN = true, int RESPF = (TRAIN ? 1 : 0), bool DB = false, typename AddrFn>
+template <typename T, int TC, int FC, int FP, bool TRAIN = true, int RESPF = (TRAIN ? 1 : 0), bool DB = false, bool PERM = false, typename AddrFn>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][FP], char* slab, const float* aff, int cbase,
                                               int chl0 /* first channel-in-tile of this wave */, int lane, AddrFn addr, const EpiSeq seq, bool use_seq,
                                               long srow = -1 /* partial row of the column sums this wave writes (p.cs_part) */) {
   // (seq by VALUE: behind a conditional pointer the struct was materialised in scratch memory in the fp16 kernels)
-#define MTBT_FAST(ACTV, MODEV) conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, RESPF, DB>(p, acc, slab, aff, cbase, chl0, lane, seq)
+#define MTBT_FAST(ACTV, MODEV)                                                                                                     \
+  do {                                                                                                                            \
+    if constexpr (PERM && (MODEV) == 0) conv_epilogue_direct<T, TC, FC, FP, ACTV>(p, acc, aff, cbase, chl0, lane, seq);           \
+    else conv_epilogue_fast<T, TC, FC, FP, ACTV, MODEV, false, RESPF, DB, PERM>(p, acc, slab, aff, cbase, chl0, lane, seq);        \
+  } while (0)
   // (fp32 storage always writes fp32: the fast bodies -- 16-bit outputs -- are not even compiled for it)
   const bool fast = sizeof(T) == 2 && use_seq && p.vec_ok && !(p.K & 7) && !p.out_f32 && p.out_mode == MTBT_OUT_NHWC;
   constexpr bool CS_OK = (((FC * 16) / 8) & ((FC * 16) / 8 - 1)) == 0;
   if constexpr (sizeof(T) == 2) {
   if (CS_OK && fast && p.cs_part && srow >= 0 && !(TRAIN && p.y2)) {   // column sums: the raw conv in front of a BatchNorm, fc2-dgrad * GELU' (d fc1 bias)
-    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, RESPF, DB>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (p.act == MTBT_ACT_NONE) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_NONE, 0, true, RESPF, DB, PERM>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
     // (16-bit storage: the polynomial derivative has the compiled body; MTBT_ACT_DGELU falls through to the general one)
-    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, RESPF, DB>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
+    if (TRAIN && p.act == MTBT_ACT_DGELU_POLY) { conv_epilogue_fast<T, TC, FC, FP, MTBT_ACT_DGELU_POLY, 2, true, RESPF, DB, PERM>(p, acc, slab, aff, cbase, chl0, lane, seq, srow); return; }
   } else if (fast && !(TRAIN && p.y2)) {
     switch (p.act) {
       case MTBT_ACT_NONE: MTBT_FAST(MTBT_ACT_NONE, 0); return;
@@ -363,7 +431,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[FC][F
   }
 #undef MTBT_FAST
   // everything else (fp32 / ragged / transposed-conv outputs, rare activation + mode pairs): the general body, run-time activation
-  conv_epilogue_body<T, TC, FC, FP, TRAIN, -1, false>(p, acc, slab, aff, cbase, chl0, lane, addr, srow);
+  conv_epilogue_body<T, TC, FC, FP, TRAIN, -1, false, PERM>(p, acc, slab, aff, cbase, chl0, lane, addr, srow);
 }
 
 }  // namespace
