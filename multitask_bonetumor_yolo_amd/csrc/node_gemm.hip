@@ -82,14 +82,17 @@ __global__ __launch_bounds__(256, 2) void node_gemm_kernel(const NodeP p) {
     st8<T>(reinterpret_cast<T*>(bimg + q * rowb + ((((c8 & 15) ^ (q & 15)) | (c8 & ~15)) << 4)), acc);
   }
 
-  // ---- this wave's weight fragments for the whole reduction: rows wave * WCH + f * 16 + lr, 16-byte piece (step g, quarter lq) ----
+  // ---- this wave's weight fragments for the whole reduction, 16-byte piece (step g, quarter lq).  Fragment row f * 16 + lr holds weight row
+  //      wave * WCH + epi_row_channel(f * 16 + lr) (conv_epilogue.h PERM): a lane's accumulators of a fragment pair are then 8 consecutive output
+  //      channels and the epilogue stores 16-byte pieces straight from them, no slab ----
+  static_assert(FC % 2 == 0, "fragment pairs (PERM epilogue)");
   uint4 a[NST][FC];
   {
-    const T* wrow = reinterpret_cast<const T*>(p.w) + (long)(wave * WCH + lr) * C + lq * 8;
+    const T* wbase = reinterpret_cast<const T*>(p.w) + (long)(wave * WCH) * C + lq * 8;
 #pragma unroll
     for (int g = 0; g < NST; ++g)
 #pragma unroll
-      for (int f = 0; f < FC; ++f) a[g][f] = *reinterpret_cast<const uint4*>(wrow + (long)f * 16 * C + g * 32);
+      for (int f = 0; f < FC; ++f) a[g][f] = *reinterpret_cast<const uint4*>(wbase + (long)epi_row_channel(f * 16 + lr) * C + g * 32);
   }
   __syncthreads();   // the whole B image is written
 
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void node_gemm_kernel(const NodeP p) {
   __syncthreads();   // every wave is done with the B image: its LDS is reused for the epilogue slabs
 
   const EpiSeq seq{pix0, 16, M, 0L, 0L};
-  conv_epilogue<T, KT, FC, FP, false>(p.ep, acc, smem + wave * (16 * PITCH), aff, 0, wave * WCH, lane,
+  conv_epilogue<T, KT, FC, FP, false, 0, false, true>(p.ep, acc, smem + wave * (16 * PITCH), aff, 0, wave * WCH, lane,
                                       [&](int j, int row, int ch, long& yoff, long& roff) -> bool {
     const long pix = pix0 + j * 16 + row;
     yoff = pix * p.ep.ldy + ch;

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256, 3) void stem_mfma_kernel(const float* __restri
     for (int ks = 0; ks < 2; ++ks) {
       const int k0 = ks * 32 + q * 8;                     // (a lane's 8 consecutive k of one weight row: two 16-byte loads, or zeros past k = 48)
       float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-      if (k0 < 48) { w0 = *reinterpret_cast<const float4*>(w + (f * 16 + nq) * 48 + k0); w1 = *reinterpret_cast<const float4*>(w + (f * 16 + nq) * 48 + k0 + 4); }
+      // fragment row f * 16 + nq holds weight row 32 (f / 2) + 8 (nq / 4) + 4 (f % 2) + nq % 4: a lane's accumulators of the fragment pair (2 m, 2 m + 1)
+      // are then the 8 consecutive channels 32 m + 8 q .. + 7 -- 16-byte stores (the same row order as conv_epilogue.h PERM / mlp_fused.hip)
+      const int wr = 32 * (f >> 1) + 8 * (nq >> 2) + 4 * (f & 1) + (nq & 3);
+      if (k0 < 48) { w0 = *reinterpret_cast<const float4*>(w + wr * 48 + k0); w1 = *reinterpret_cast<const float4*>(w + wr * 48 + k0 + 4); }
       afr[f][ks] = uint4{pk16<HT>(w0.x, w0.y), pk16<HT>(w0.z, w0.w), pk16<HT>(w1.x, w1.y), pk16<HT>(w1.z, w1.w)};
     }
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void stem_mfma_kernel(const float* __restri
       acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[f] = mfma_16x16x32<HT>(afr[f][0], bfr[0], acc[f]);
       acc[f] = mfma_16x16x32<HT>(afr[f][1], bfr[1], acc[f]);
-      const float4 bv = *reinterpret_cast<const float4*>(bias + f * 16 + q * 4);
+      const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * (f >> 1) + 8 * q + 4 * (f & 1));
       acc[f][0] += bv.x; acc[f][1] += bv.y; acc[f][2] += bv.z; acc[f][3] += bv.w;
       s += (acc[f][0] + acc[f][1]) + (acc[f][2] + acc[f][3]);
     }
@@ -165,24 +168,28 @@ __global__ __launch_bounds__(256, 3) void stem_mfma_kernel(const float* __restri
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     const float rstd = rsqrtf(v * (1.0f / Cout) + eps);
+    static_assert(FCH % 2 == 0, "fragment pairs");
     if (raw) {   // training: the LayerNorm input
-      HT* ro = raw + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
+      HT* ro = raw + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 8;
 #pragma unroll
-      for (int f = 0; f < FCH; ++f) {
-        uint2 o;
-        o.x = pk16<HT>(acc[f][0], acc[f][1]);
-        o.y = pk16<HT>(acc[f][2], acc[f][3]);
-        *reinterpret_cast<uint2*>(ro + f * 16) = o;
-      }
+      for (int m = 0; m < FCH / 2; ++m)
+        *reinterpret_cast<u32x4*>(ro + m * 32) = u32x4{pk16<HT>(acc[2 * m][0], acc[2 * m][1]), pk16<HT>(acc[2 * m][2], acc[2 * m][3]),
+                                                        pk16<HT>(acc[2 * m + 1][0], acc[2 * m + 1][1]), pk16<HT>(acc[2 * m + 1][2], acc[2 * m + 1][3])};
     }
-    HT* yo = y + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 4;
+    HT* yo = y + (((long)n * Ho + oy) * Wo + ox) * Cout + q * 8;
 #pragma unroll
-    for (int f = 0; f < FCH; ++f) {
-      const float4 gw = *reinterpret_cast<const float4*>(lnw + f * 16 + q * 4), gb = *reinterpret_cast<const float4*>(lnb + f * 16 + q * 4);
-      uint2 o;
-      o.x = pk16<HT>((acc[f][0] - mean) * rstd * gw.x + gb.x, (acc[f][1] - mean) * rstd * gw.y + gb.y);
-      o.y = pk16<HT>((acc[f][2] - mean) * rstd * gw.z + gb.z, (acc[f][3] - mean) * rstd * gw.w + gb.w);
-      *reinterpret_cast<uint2*>(yo + f * 16) = o;
+    for (int m = 0; m < FCH / 2; ++m) {
+      const float* gwp = lnw + m * 32 + q * 8;
+      const float* gbp = lnb + m * 32 + q * 8;
+      const float4 w0 = *reinterpret_cast<const float4*>(gwp), w1 = *reinterpret_cast<const float4*>(gwp + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(gbp), b1 = *reinterpret_cast<const float4*>(gbp + 4);
+      const f32x4 a0 = acc[2 * m], a1 = acc[2 * m + 1];
+      u32x4 o;
+      o.x = pk16<HT>((a0[0] - mean) * rstd * w0.x + b0.x, (a0[1] - mean) * rstd * w0.y + b0.y);
+      o.y = pk16<HT>((a0[2] - mean) * rstd * w0.z + b0.z, (a0[3] - mean) * rstd * w0.w + b0.w);
+      o.z = pk16<HT>((a1[0] - mean) * rstd * w1.x + b1.x, (a1[1] - mean) * rstd * w1.y + b1.y);
+      o.w = pk16<HT>((a1[2] - mean) * rstd * w1.z + b1.z, (a1[3] - mean) * rstd * w1.w + b1.w);
+      *reinterpret_cast<u32x4*>(yo + m * 32) = o;
     }
   }
 }
